@@ -1,0 +1,140 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (/root/reference) on CPU.
+
+Run in the build container only:   python -m oracle.make_goldens [--only NAME]
+
+Every fixture holds: the case description (config name + override list + weight seed + image
+seed/shape - all inputs are regenerated from seeds by the tests), the sha256 of the synthetic
+weights, the reference's 8-key output dict, the visualiser's labels/uv per detection
+(/root/reference/visualizer.py:10-56) and, for the "stages" cases, intermediate tensors captured
+with forward hooks on the reference's modules. Nothing of the reference's source is stored.
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from densepose_torchscript_amd.config import TINY_OPTS, get_config  # noqa: E402
+from densepose_torchscript_amd.weights import make_synthetic_state, state_checksum  # noqa: E402
+from oracle.ref_import import REFERENCE_ROOT, build_reference_predictor  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+TINY = TINY_OPTS + ["MODEL.ROI_DENSEPOSE_HEAD.POOLER_RESOLUTION", 7, "TEST.DETECTIONS_PER_IMAGE", 3]
+
+# name -> (config, opts, weight seed, image seed, (H, W), capture stages?, IUV subsample stride)
+CASES = {
+    "tiny_r50_s1x_a": ("densepose_rcnn_R_50_FPN_s1x", TINY, 0, 11, (96, 160), True, 1),
+    "tiny_r50_s1x_b": ("densepose_rcnn_R_50_FPN_s1x", TINY, 0, 12, (250, 140), False, 1),
+    "tiny_r50_legacy": ("densepose_rcnn_R_50_FPN_s1x_legacy", TINY, 1, 13, (120, 200), True, 1),
+    "tiny_r101_s1x": ("densepose_rcnn_R_101_FPN_s1x", TINY, 2, 14, (128, 128), False, 1),
+    "tiny_r50_dl": ("densepose_rcnn_R_50_FPN_DL_s1x", TINY, 3, 15, (96, 160), True, 1),
+    "tiny_r101_dl": ("densepose_rcnn_R_101_FPN_DL_s1x", TINY, 4, 16, (300, 500), False, 1),
+    # full-width network, reduced frame (CPU-oracle replay in a few seconds)
+    "full_r50_s1x_small": ("densepose_rcnn_R_50_FPN_s1x",
+                           ["INPUT.MIN_SIZE_TEST", 256, "INPUT.MAX_SIZE_TEST", 448, "TEST.DETECTIONS_PER_IMAGE", 4],
+                           0, 21, (256, 400), False, 4),
+    # BASELINE.json configs[1] geometry: 800x1333 frame, R pinned to 8
+    "full_r50_s1x_800x1333": ("densepose_rcnn_R_50_FPN_s1x", ["TEST.DETECTIONS_PER_IMAGE", 8], 0, 1234, (800, 1333), False, 8),
+}
+
+
+def make_image(seed, hw):
+    return np.random.default_rng(seed).integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)
+
+
+def _import_visualizer():
+    if "cv2" not in sys.modules:  # cv2 is absent here; the drawing code that needs it is never called
+        stub = types.ModuleType("cv2")
+        stub.__getattr__ = lambda name: 0
+        sys.modules["cv2"] = stub
+    sys.path.insert(0, REFERENCE_ROOT)
+    import visualizer  # noqa
+    return visualizer
+
+
+def run_case(name):
+    cfg_name, opts, wseed, iseed, hw, stages, sub = CASES[name]
+    cfg = get_config(cfg_name, opts)
+    state = make_synthetic_state(cfg, wseed)
+    pred = build_reference_predictor(cfg, state)
+    model = pred.model
+    cap = {}
+    hooks = []
+    if stages:
+        def hook(nm):
+            def fn(mod, inp, out):
+                cap[nm] = out
+            return fn
+        hooks.append(model.backbone.register_forward_hook(hook("features")))
+        hooks.append(model.proposal_generator.register_forward_hook(hook("proposals")))
+        hooks.append(model.proposal_generator.rpn_head.register_forward_hook(hook("rpn_head")))
+        hooks.append(model.roi_heads.box_pooler.register_forward_hook(hook("box_pooled")))
+        hooks.append(model.roi_heads.box_predictor.register_forward_hook(hook("box_predictor")))
+        if model.roi_heads.decoder is not None:
+            hooks.append(model.roi_heads.decoder.register_forward_hook(hook("decoder_out")))
+        hooks.append(model.roi_heads.densepose_pooler.register_forward_hook(hook("dp_pooled")))
+        hooks.append(model.roi_heads.densepose_head.register_forward_hook(hook("dp_head_out")))
+    img = torch.from_numpy(make_image(iseed, hw))
+    out = pred(img)
+    for h in hooks:
+        h.remove()
+    arrays = {}
+    for k, v in out.items():
+        a = v.numpy()
+        if k.startswith("pred_densepose") and sub > 1:
+            a = a[:, :, ::sub, ::sub]
+        arrays["out/" + k] = a
+    # part-index argmax + uv as the visualiser computes them
+    vis = _import_visualizer()
+    results, _ = vis.DensePoseResultExtractor()(out)
+    for i, r in enumerate(results):
+        arrays["vis/labels_%d" % i] = r["labels"].numpy().astype(np.uint8)
+        arrays["vis/uv_%d" % i] = r["uv"].numpy()
+    if stages:
+        for k, v in cap["features"].items():
+            arrays["stage/" + k] = v.numpy()
+        props = cap["proposals"][0][0]
+        arrays["stage/proposal_boxes"] = props["proposal_boxes"].numpy()
+        arrays["stage/objectness_logits"] = props["objectness_logits"].numpy()
+        logits, deltas = cap["rpn_head"]
+        for i, (l, d) in enumerate(zip(logits, deltas)):
+            arrays["stage/rpn_logits_%d" % i] = l.numpy()
+            arrays["stage/rpn_deltas_%d" % i] = d.numpy()
+        arrays["stage/box_pooled"] = cap["box_pooled"].numpy()
+        arrays["stage/box_logits"] = cap["box_predictor"][0].numpy()
+        arrays["stage/box_deltas"] = cap["box_predictor"][1].numpy()
+        if "decoder_out" in cap:
+            arrays["stage/decoder_out"] = cap["decoder_out"].numpy()
+        arrays["stage/dp_pooled"] = cap["dp_pooled"].numpy()
+        arrays["stage/dp_head_out"] = cap["dp_head_out"].numpy()
+    meta = dict(case=name, config=cfg_name, opts=list(opts), weight_seed=wseed, image_seed=iseed, image_hw=list(hw),
+                iuv_stride=sub, weights_sha256=state_checksum(state), torch=torch.__version__,
+                generator="oracle/make_goldens.py (reference imported from /root/reference)")
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(GOLDEN_DIR, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-26s R=%d  %.2f MB" % (name, len(out["scores"]), os.path.getsize(path) / 1e6), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    torch.set_num_threads(os.cpu_count() or 1)
+    for name in CASES:
+        if args.only and args.only != name:
+            continue
+        run_case(name)
+
+
+if __name__ == "__main__":
+    main()
