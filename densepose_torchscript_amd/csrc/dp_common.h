@@ -1,0 +1,74 @@
+// Shared device/host helpers for the gfx950 DensePose kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/densepose_hip.h"
+
+// ---- error reporting (host) -------------------------------------------------------------------
+extern thread_local char dp_err_buf[512];
+inline int dp_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(dp_err_buf, sizeof(dp_err_buf), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define DP_REQUIRE(cond, ...)                                   \
+  do {                                                          \
+    if (!(cond)) return dp_fail(DP_ERR_BAD_ARG, __VA_ARGS__);   \
+  } while (0)
+inline int dp_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dp_fail(DP_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return DP_OK;
+}
+
+// ---- bf16 <-> f32 (device) -----------------------------------------------------------------------
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) { return __builtin_bit_cast(float, lo16 << 16); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
+  bf16_t ha = (bf16_t)a, hb = (bf16_t)b;
+  return (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int kDtype = DP_F32;
+  static constexpr int kChunk = 4;  // elements per 16-byte chunk
+  __device__ static __forceinline__ float load(const float* p) { return *p; }
+  __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <>
+struct Elem<uint16_t> {  // bf16 storage
+  static constexpr int kDtype = DP_BF16;
+  static constexpr int kChunk = 8;
+  __device__ static __forceinline__ float load(const uint16_t* p) { return bf16_bits_to_f32(*p); }
+  __device__ static __forceinline__ void store(uint16_t* p, float v) {
+    bf16_t h = (bf16_t)v;
+    *p = __builtin_bit_cast(uint16_t, h);
+  }
+};
+
+// load / store 4 consecutive channels (8-byte aligned for bf16, 16-byte for f32)
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const uint16_t* p) {
+  uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(bf16_bits_to_f32(u.x & 0xffffu), bf16_bits_to_f32(u.x >> 16), bf16_bits_to_f32(u.y & 0xffffu),
+                     bf16_bits_to_f32(u.y >> 16));
+}
+__device__ __forceinline__ void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(uint16_t* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+}
+
+static inline hipStream_t as_stream(dp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,621 @@
+// Proposal / detection selection kernels: RPN top-k + decode, batched greedy NMS (wavefront bitmask),
+// NHWC ROIAlign, second-stage decode + score filter, box post-processing.
+// All box arithmetic is fp32 with FMA contraction OFF and IEEE division so that IoU / clip / level
+// decisions follow the reference's CPU ops bit for bit wherever the inputs are equal.
+#include "dp_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ uint32_t f32_to_key(float f) {  // monotonic: larger float -> larger key
+  const uint32_t u = __builtin_bit_cast(uint32_t, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_f32(uint32_t k) {
+  const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __builtin_bit_cast(float, u);
+}
+__device__ __forceinline__ bool finitef(float x) { return fabsf(x) <= 3.402823466e+38f; }
+
+// In-LDS bitonic sort, descending, of n2 (power of two) 64-bit keys with `nthreads` threads.
+__device__ void bitonic_sort_desc(unsigned long long* s, int n2, int tid, int nthreads) {
+  for (int size = 2; size <= n2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < (n2 >> 1); t += nthreads) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = s[lo], b = s[hi];
+        if (desc ? (a < b) : (a > b)) {
+          s[lo] = b;
+          s[hi] = a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// =====================================================================================================
+// K9 + K8: per (image, level) top-k of the objectness logits, then decode of the survivors only.
+// =====================================================================================================
+constexpr int kSelThreads = 1024;
+
+__global__ void rpn_keys_kernel(const float* __restrict__ head, uint32_t* __restrict__ keys, int n_img, int cells, int A, int head_c) {
+  const long long total = (long long)n_img * cells * A;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int a = (int)(i % A);
+    const long long cell = i / A;  // img*cells + cell
+    keys[i] = f32_to_key(head[cell * head_c + a]);
+  }
+}
+
+struct RpnSelArgs {
+  const float* head;
+  const uint32_t* keys;
+  int n_img, Hi, Wi, A, head_c, stride_px, level, kmax, slot_off, slots_per_img;
+  float ca[3][4];
+  float clip_x, clip_y;
+  float* cand_boxes;
+  float* cand_scores;
+  int32_t* cand_level;
+  int32_t* cand_valid;
+};
+
+__global__ __launch_bounds__(kSelThreads) void rpn_select_kernel(const RpnSelArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem_raw);  // [n2]
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int sh_prefix, sh_need, sh_count, sh_eq_total, sh_eq_taken;
+  __shared__ unsigned int wave_sums[kSelThreads / 64];
+
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int n = p.Hi * p.Wi * p.A;
+  const int k = n < p.kmax ? n : p.kmax;
+  int n2 = 1;
+  while (n2 < k) n2 <<= 1;
+  const uint32_t* keys = p.keys + (long long)img * n;
+
+  for (int i = tid; i < n2; i += kSelThreads) sel[i] = 0ull;
+  if (tid == 0) { sh_count = 0; sh_eq_taken = 0; }
+  __syncthreads();
+
+  if (n <= p.kmax) {
+    for (int i = tid; i < n; i += kSelThreads) sel[i] = ((unsigned long long)keys[i] << 32) | (uint32_t)(~(uint32_t)i);
+  } else {
+    // ---- radix select (4 x 8 bits, MSB first) of the k-th largest key ----
+    uint32_t prefix = 0, mask = 0;
+    unsigned int need = (unsigned)k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      for (int i = tid; i < 256; i += kSelThreads) hist[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < n; i += kSelThreads) {
+        const uint32_t key = keys[i];
+        if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned int acc = 0;
+        int d = 255;
+        for (; d > 0; --d) {
+          if (acc + hist[d] >= need) break;
+          acc += hist[d];
+        }
+        sh_prefix = prefix | ((uint32_t)d << shift);
+        sh_need = need - acc;       // how many are still needed inside bucket d
+        sh_eq_total = hist[d];
+      }
+      __syncthreads();
+      prefix = sh_prefix;
+      need = sh_need;
+      mask |= 255u << shift;
+      __syncthreads();
+    }
+    const uint32_t T = prefix;             // k-th largest key
+    const unsigned int need_eq = need;     // number of entries == T to take
+    const unsigned int eq_total = sh_eq_total;
+    // ---- gather keys > T (any order: they are sorted afterwards) ----
+    for (int i = tid; i < n; i += kSelThreads) {
+      const uint32_t key = keys[i];
+      if (key > T || (key == T && need_eq == eq_total)) {
+        const unsigned int pos = atomicAdd(&sh_count, 1u);
+        sel[pos] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)i);
+      }
+    }
+    __syncthreads();
+    if (need_eq != eq_total) {
+      // ties at the threshold: take the need_eq lowest indices (deterministic), ordered block scan
+      const unsigned int base = sh_count;
+      for (int i0 = 0; i0 < n; i0 += kSelThreads) {
+        const int i = i0 + tid;
+        const bool f = (i < n) && (keys[i] == T);
+        const unsigned long long bal = __ballot(f);
+        const int lane = tid & 63, w = tid >> 6;
+        if (lane == 0) wave_sums[w] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned int before = sh_eq_taken;
+        for (int ww = 0; ww < w; ++ww) before += wave_sums[ww];
+        const unsigned int my = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        if (f && my < need_eq) sel[base + my] = ((unsigned long long)T << 32) | (uint32_t)(~(uint32_t)i);
+        __syncthreads();
+        if (tid == 0) {
+          unsigned int tot = 0;
+          for (int ww = 0; ww < kSelThreads / 64; ++ww) tot += wave_sums[ww];
+          sh_eq_taken += tot;
+        }
+        __syncthreads();
+        if (sh_eq_taken >= need_eq) break;
+      }
+    }
+  }
+  bitonic_sort_desc(sel, n2, tid, kSelThreads);
+
+  // ---- decode the k survivors (box_regression.py:74-112 with weights (1,1,1,1); anchors analytic) ----
+  const float clampv = 4.135166556742356f;  // log(1000/16)
+  for (int j = tid; j < p.kmax; j += kSelThreads) {
+    const long long slot = (long long)img * p.slots_per_img + p.slot_off + j;
+    if (j >= k) {
+      p.cand_valid[slot] = 0;
+      p.cand_scores[slot] = 0.f;
+      p.cand_level[slot] = p.level;
+      p.cand_boxes[slot * 4 + 0] = 0.f; p.cand_boxes[slot * 4 + 1] = 0.f; p.cand_boxes[slot * 4 + 2] = 0.f; p.cand_boxes[slot * 4 + 3] = 0.f;
+      continue;
+    }
+    const unsigned long long e = sel[j];
+    const float score = key_to_f32((uint32_t)(e >> 32));
+    const int idx = (int)(~(uint32_t)(e & 0xffffffffull));
+    const int a = idx % p.A;
+    const int cell = idx / p.A;
+    const int x = cell % p.Wi, y = cell / p.Wi;
+    const float sx = (float)(x * p.stride_px), sy = (float)(y * p.stride_px);
+    const float ax1 = sx + p.ca[a][0], ay1 = sy + p.ca[a][1], ax2 = sx + p.ca[a][2], ay2 = sy + p.ca[a][3];
+    const float* d = p.head + ((long long)img * p.Hi * p.Wi + cell) * p.head_c + p.A + a * 4;
+    const float widths = ax2 - ax1, heights = ay2 - ay1;
+    const float ctr_x = ax1 + 0.5f * widths, ctr_y = ay1 + 0.5f * heights;
+    const float dx = d[0], dy = d[1];
+    const float dw = fminf(d[2], clampv), dh = fminf(d[3], clampv);
+    const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+    const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+    float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+    bool ok = finitef(x1) && finitef(y1) && finitef(x2) && finitef(y2) && finitef(score) && !(d[2] != d[2]) && !(d[3] != d[3]);
+    // Q1: x clamped to clip_x (= padded HEIGHT), y to clip_y (= padded WIDTH)
+    x1 = fminf(fmaxf(x1, 0.f), p.clip_x); y1 = fminf(fmaxf(y1, 0.f), p.clip_y);
+    x2 = fminf(fmaxf(x2, 0.f), p.clip_x); y2 = fminf(fmaxf(y2, 0.f), p.clip_y);
+    ok = ok && ((x2 - x1) >= 0.f) && ((y2 - y1) >= 0.f);
+    p.cand_boxes[slot * 4 + 0] = x1; p.cand_boxes[slot * 4 + 1] = y1; p.cand_boxes[slot * 4 + 2] = x2; p.cand_boxes[slot * 4 + 3] = y2;
+    p.cand_scores[slot] = score;
+    p.cand_level[slot] = p.level;
+    p.cand_valid[slot] = ok ? 1 : 0;
+  }
+}
+
+// =====================================================================================================
+// K10 / K13: batched greedy NMS. sort (1 workgroup / image) -> 64x64 bitmask tiles -> wavefront scan.
+// =====================================================================================================
+struct NmsWs {
+  float* sboxes;        // [n_img][n_slots][4] boxes in score order (+ coordinate-trick offsets when applicable)
+  int32_t* sgroup;      // [n_img][n_slots]
+  int32_t* sslot;       // [n_img][n_slots]
+  int32_t* nvalid;      // [n_img] (+ padding)
+  unsigned long long* mask;  // [n_img][n_slots][ncb]
+};
+__host__ __device__ inline long long align256(long long x) { return (x + 255) & ~255ll; }
+inline NmsWs carve_nms_ws(void* ws, int n_img, int n_slots) {
+  unsigned char* b = reinterpret_cast<unsigned char*>(ws);
+  NmsWs w;
+  long long off = 0;
+  w.sboxes = reinterpret_cast<float*>(b + off); off = align256(off + (long long)n_img * n_slots * 16);
+  w.sgroup = reinterpret_cast<int32_t*>(b + off); off = align256(off + (long long)n_img * n_slots * 4);
+  w.sslot = reinterpret_cast<int32_t*>(b + off); off = align256(off + (long long)n_img * n_slots * 4);
+  w.nvalid = reinterpret_cast<int32_t*>(b + off); off = align256(off + (long long)n_img * 4);
+  w.mask = reinterpret_cast<unsigned long long*>(b + off);
+  return w;
+}
+
+constexpr int kSortThreads = 1024;
+
+__global__ __launch_bounds__(kSortThreads) void nms_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                                 const int32_t* __restrict__ group, const int32_t* __restrict__ valid,
+                                                                 int n_slots, int n2, int trick_max_numel, NmsWs w) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long* s = reinterpret_cast<unsigned long long*>(smem_raw);
+  __shared__ unsigned int sh_nvalid;
+  __shared__ float red[kSortThreads];
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const long long base = (long long)img * n_slots;
+  if (tid == 0) sh_nvalid = 0;
+  __syncthreads();
+  float mx = -INFINITY;
+  unsigned int cnt = 0;
+  for (int i = tid; i < n2; i += kSortThreads) {
+    unsigned long long e = 0ull;
+    if (i < n_slots && valid[base + i]) {
+      // +1 keeps every valid key above the 0 used for padding / invalid entries
+      e = ((unsigned long long)f32_to_key(scores[base + i]) << 32) | (uint32_t)(~(uint32_t)i);
+      ++cnt;
+      const float* b = boxes + (base + i) * 4;
+      mx = fmaxf(mx, fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+    }
+    s[i] = e;
+  }
+  if (cnt) atomicAdd(&sh_nvalid, cnt);
+  red[tid] = mx;
+  __syncthreads();
+  for (int o = kSortThreads / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+    __syncthreads();
+  }
+  const float max_coord = red[0];
+  const int nvalid = (int)sh_nvalid;
+  bitonic_sort_desc(s, n2, tid, kSortThreads);
+  const bool trick = (4 * nvalid <= trick_max_numel);
+  const float off_unit = max_coord + 1.0f;
+  for (int i = tid; i < n_slots; i += kSortThreads) {
+    if (i < nvalid) {
+      const int slot = (int)(~(uint32_t)(s[i] & 0xffffffffull));
+      const float* b = boxes + (base + slot) * 4;
+      const int g = group[base + slot];
+      float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
+      if (trick) {
+        const float o = (float)g * off_unit;  // torchvision: boxes + idxs.to(boxes) * (boxes.max() + 1)
+        x1 = x1 + o; y1 = y1 + o; x2 = x2 + o; y2 = y2 + o;
+      }
+      float* d = w.sboxes + (base + i) * 4;
+      d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2;
+      w.sgroup[base + i] = trick ? 0 : g;  // with the trick, overlap across groups is impossible by construction
+      w.sslot[base + i] = slot;
+    } else {
+      w.sslot[base + i] = -1;
+    }
+  }
+  if (tid == 0) w.nvalid[img] = nvalid;
+}
+
+__global__ __launch_bounds__(64) void nms_mask_kernel(int n_slots, int ncb, float thr, NmsWs w) {
+  const int cb = blockIdx.x, rb = blockIdx.y, img = blockIdx.z;
+  if (cb < rb) return;
+  const int nvalid = w.nvalid[img];
+  if (rb * 64 >= nvalid) return;
+  const long long base = (long long)img * n_slots;
+  __shared__ float cbx[64][4];
+  __shared__ int cgrp[64];
+  const int t = threadIdx.x;
+  {
+    const int j = cb * 64 + t;
+    if (j < nvalid) {
+      const float* b = w.sboxes + (base + j) * 4;
+      cbx[t][0] = b[0]; cbx[t][1] = b[1]; cbx[t][2] = b[2]; cbx[t][3] = b[3];
+      cgrp[t] = w.sgroup[base + j];
+    }
+  }
+  __syncthreads();
+  const int i = rb * 64 + t;
+  unsigned long long bits = 0ull;
+  if (i < nvalid) {
+    const float* b = w.sboxes + (base + i) * 4;
+    const float ix1 = b[0], iy1 = b[1], ix2 = b[2], iy2 = b[3];
+    const int ig = w.sgroup[base + i];
+    const float iarea = (ix2 - ix1) * (iy2 - iy1);
+    const int jmax = min(64, nvalid - cb * 64);
+    for (int jj = 0; jj < jmax; ++jj) {
+      const int j = cb * 64 + jj;
+      if (j <= i || cgrp[jj] != ig) continue;
+      const float jx1 = cbx[jj][0], jy1 = cbx[jj][1], jx2 = cbx[jj][2], jy2 = cbx[jj][3];
+      const float jarea = (jx2 - jx1) * (jy2 - jy1);
+      const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1), xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
+      const float ww = fmaxf(0.f, xx2 - xx1), hh = fmaxf(0.f, yy2 - yy1);
+      const float inter = ww * hh;
+      const float ovr = inter / (iarea + jarea - inter);
+      if (ovr > thr) bits |= (1ull << jj);
+    }
+    w.mask[(base + i) * ncb + cb] = bits;
+  }
+}
+
+__global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int n_slots,
+                                                       int ncb, int max_out, NmsWs w, float* __restrict__ out_boxes,
+                                                       float* __restrict__ out_scores, int32_t* __restrict__ out_index,
+                                                       int32_t* __restrict__ out_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long* remv = reinterpret_cast<unsigned long long*>(smem_raw);  // [ncb]
+  const int img = blockIdx.x, lane = threadIdx.x;
+  const long long base = (long long)img * n_slots;
+  const int nvalid = w.nvalid[img];
+  for (int i = lane; i < ncb; i += 64) remv[i] = 0ull;
+  __syncthreads();
+  int kept = 0;
+  const int nchunks = (nvalid + 63) / 64;
+  for (int c = 0; c < nchunks && kept < max_out; ++c) {
+    const int row = c * 64 + lane;
+    const bool rvalid = row < nvalid;
+    const unsigned long long D = rvalid ? w.mask[(base + row) * ncb + c] : 0ull;
+    unsigned long long cur = remv[c];
+    unsigned long long km = 0ull;
+    const int rows_here = min(64, nvalid - c * 64);
+    for (int j = 0; j < rows_here; ++j) {
+      const unsigned long long dj = __shfl(D, j);  // wave-uniform
+      if (!((cur >> j) & 1ull)) {
+        km |= (1ull << j);
+        cur |= dj;
+      }
+    }
+    // emit kept rows of this chunk in order
+    const bool mine = rvalid && ((km >> lane) & 1ull);
+    const int pos = kept + (int)__popcll(km & ((1ull << lane) - 1ull));
+    if (mine && pos < max_out) {
+      const int slot = w.sslot[base + row];
+      const long long o = (long long)img * max_out + pos;
+      const float* b = boxes + (base + slot) * 4;
+      out_boxes[o * 4 + 0] = b[0]; out_boxes[o * 4 + 1] = b[1]; out_boxes[o * 4 + 2] = b[2]; out_boxes[o * 4 + 3] = b[3];
+      out_scores[o] = scores[base + slot];
+      out_index[o] = slot;
+    }
+    kept += (int)__popcll(km);
+    // OR the kept rows' masks into the removal words of later chunks (lane <-> word)
+    if (c + 1 < nchunks && kept < max_out) {
+      for (int wd = c + 1 + lane; wd < ncb; wd += 64) {
+        unsigned long long acc = remv[wd];
+        unsigned long long m = km;
+        while (m) {
+          const int j = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          acc |= w.mask[(base + c * 64 + j) * ncb + wd];
+        }
+        remv[wd] = acc;
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) out_count[img] = kept < max_out ? kept : max_out;
+}
+
+// =====================================================================================================
+// K11 / K15: ROIAlign (aligned=False, legacy pixel model), NHWC, one workgroup per (roi, bin row)
+// =====================================================================================================
+struct RoiArgs {
+  const void* feat[4];
+  int Hl[4], Wl[4];
+  float scale[4];
+  int n_levels, min_level, C, P, sampling;
+  const float* boxes;
+  const int32_t* counts;
+  int n_img, max_rois;
+  void* out;
+  int compact;
+  const int32_t* roi_offsets;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs p) {
+  const int img = blockIdx.z, j = blockIdx.y, py = blockIdx.x;
+  if (j >= p.counts[img]) return;
+  const float* b = p.boxes + ((long long)img * p.max_rois + j) * 4;
+  const float bx1 = b[0], by1 = b[1], bx2 = b[2], by2 = b[3];
+  int lvl = 0;
+  if (p.n_levels > 1) {
+    // poolers.py:43-51
+    const float area = (bx2 - bx1) * (by2 - by1);
+    const float sz = sqrtf(area);
+    float lv = floorf(4.0f + log2f(sz / 224.0f + 1e-8f));
+    const float lo = (float)p.min_level, hi = (float)(p.min_level + p.n_levels - 1);
+    lv = fminf(fmaxf(lv, lo), hi);   // NaN (negative area) -> fmaxf returns lo, torch.clamp would give NaN->int; never happens (w,h >= 0)
+    lvl = (int)lv - p.min_level;
+  }
+  const int H = p.Hl[lvl], W = p.Wl[lvl], C = p.C, P = p.P, g = p.sampling;
+  const float scale = p.scale[lvl];
+  const T* __restrict__ feat = reinterpret_cast<const T*>(p.feat[lvl]) + (long long)img * H * W * C;
+  const float rsw = bx1 * scale, rsh = by1 * scale, rew = bx2 * scale, reh = by2 * scale;
+  const float roi_w = fmaxf(rew - rsw, 1.0f), roi_h = fmaxf(reh - rsh, 1.0f);
+  const float bin_h = roi_h / (float)P, bin_w = roi_w / (float)P;
+  const float count = (float)(g * g > 1 ? g * g : 1);
+  const long long orow = p.compact ? (long long)(p.roi_offsets[img] + j) : ((long long)img * p.max_rois + j);
+  T* __restrict__ out = reinterpret_cast<T*>(p.out) + (orow * P + py) * (long long)P * C;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int C4 = C >> 2;
+  for (int px = wave; px < P; px += 4) {
+    for (int c4 = lane; c4 < C4; c4 += 64) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int iy = 0; iy < g; ++iy) {
+        const float yy = rsh + (float)py * bin_h + ((float)iy + 0.5f) * bin_h / (float)g;
+        for (int ix = 0; ix < g; ++ix) {
+          const float xx = rsw + (float)px * bin_w + ((float)ix + 0.5f) * bin_w / (float)g;
+          float y = yy, x = xx;
+          if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;  // contributes 0
+          if (y <= 0.f) y = 0.f;
+          if (x <= 0.f) x = 0.f;
+          int y_low = (int)y, x_low = (int)x, y_high, x_high;
+          if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+          if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+          const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+          const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+          const float4 v1 = load4(feat + ((long long)y_low * W + x_low) * C + c4 * 4);
+          const float4 v2 = load4(feat + ((long long)y_low * W + x_high) * C + c4 * 4);
+          const float4 v3 = load4(feat + ((long long)y_high * W + x_low) * C + c4 * 4);
+          const float4 v4 = load4(feat + ((long long)y_high * W + x_high) * C + c4 * 4);
+          acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+          acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+          acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+          acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+        }
+      }
+      acc.x /= count; acc.y /= count; acc.z /= count; acc.w /= count;
+      store4(out + (long long)px * C + c4 * 4, acc);
+    }
+  }
+}
+
+// =====================================================================================================
+// K13 (first half): softmax + apply_deltas + finite filter + score threshold
+// =====================================================================================================
+__global__ void box_decode_kernel(const dp_box_decode_params p) {
+  const int total = p.n_img * p.max_rois;
+  const float clampv = 4.135166556742356f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int img = i / p.max_rois, j = i - img * p.max_rois;
+    bool ok = j < p.prop_counts[img];
+    float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, p0 = 0.f;
+    if (ok) {
+      const float* l = p.logits + (long long)i * p.ld;
+      const float l0 = l[0], l1 = l[1];
+      const float m = fmaxf(l0, l1);
+      const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+      const float sum = e0 + e1;
+      p0 = e0 / sum;
+      const float p1 = e1 / sum;
+      const float* b = p.prop_boxes + (long long)i * 4;
+      const float widths = b[2] - b[0], heights = b[3] - b[1];
+      const float ctr_x = b[0] + 0.5f * widths, ctr_y = b[1] + 0.5f * heights;
+      const float dx = l[2] / p.wx, dy = l[3] / p.wy;
+      const float dw = fminf(l[4] / p.ww, clampv), dh = fminf(l[5] / p.wh, clampv);
+      const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+      const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+      x1 = pcx - 0.5f * pw; y1 = pcy - 0.5f * ph; x2 = pcx + 0.5f * pw; y2 = pcy + 0.5f * ph;
+      ok = finitef(x1) && finitef(y1) && finitef(x2) && finitef(y2) && finitef(p0) && finitef(p1) && (l[4] == l[4]) && (l[5] == l[5]);
+      ok = ok && (p0 > p.score_thresh);  // Q2: boxes are NOT clipped here
+    }
+    p.cand_boxes[(long long)i * 4 + 0] = x1; p.cand_boxes[(long long)i * 4 + 1] = y1;
+    p.cand_boxes[(long long)i * 4 + 2] = x2; p.cand_boxes[(long long)i * 4 + 3] = y2;
+    p.cand_scores[i] = p0;
+    p.cand_group[i] = 0;
+    p.cand_valid[i] = ok ? 1 : 0;
+  }
+}
+
+__global__ void postprocess_kernel(const dp_postprocess_params p) {
+  const int total = p.n_img * p.max_dets;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int img = i / p.max_dets, j = i - img * p.max_dets;
+    int keep = 0;
+    float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
+    if (j < p.counts[img]) {
+      const float sx = p.scale_xy[img * 2 + 0], sy = p.scale_xy[img * 2 + 1];
+      const float H = p.out_hw[img * 2 + 0], W = p.out_hw[img * 2 + 1];
+      const float* b = p.boxes + (long long)i * 4;
+      x1 = b[0] * sx; y1 = b[1] * sy; x2 = b[2] * sx; y2 = b[3] * sy;
+      keep = ((x2 - x1) >= 0.f && (y2 - y1) >= 0.f) ? 1 : 0;
+      x1 = fminf(fmaxf(x1, 0.f), W); y1 = fminf(fmaxf(y1, 0.f), H);
+      x2 = fminf(fmaxf(x2, 0.f), W); y2 = fminf(fmaxf(y2, 0.f), H);
+    }
+    p.out_boxes[(long long)i * 4 + 0] = x1; p.out_boxes[(long long)i * 4 + 1] = y1;
+    p.out_boxes[(long long)i * 4 + 2] = x2; p.out_boxes[(long long)i * 4 + 3] = y2;
+    p.keep[i] = keep;
+  }
+}
+
+inline int next_pow2(int v) {
+  int n = 1;
+  while (n < v) n <<= 1;
+  return n;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------
+extern "C" int64_t dp_rpn_topk_workspace_bytes(int n_img, int Hi, int Wi, int A) {
+  return (int64_t)n_img * Hi * Wi * A * 4;  // compact sortable keys of one level
+}
+
+extern "C" int dp_rpn_topk_decode(const dp_rpn_level_params* p, dp_stream_t stream) {
+  DP_REQUIRE(p, "dp_rpn_topk_decode: null params");
+  DP_REQUIRE(p->head && p->cand_boxes && p->cand_scores && p->cand_level && p->cand_valid && p->workspace, "dp_rpn_topk_decode: null pointer");
+  DP_REQUIRE(p->n_img > 0 && p->Hi > 0 && p->Wi > 0 && p->A > 0 && p->A <= 3 && p->head_c >= 5 * p->A, "dp_rpn_topk_decode: bad shape");
+  DP_REQUIRE(p->kmax > 0 && p->kmax <= 4096, "dp_rpn_topk_decode: kmax=%d outside (0, 4096]", p->kmax);
+  DP_REQUIRE(p->slot_off >= 0 && p->slot_off + p->kmax <= p->slots_per_img, "dp_rpn_topk_decode: slot range");
+  const long long n = (long long)p->Hi * p->Wi * p->A;
+  DP_REQUIRE(n < (1ll << 30), "dp_rpn_topk_decode: level too large");
+  hipStream_t s = as_stream(stream);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(p->workspace);
+  const long long total = n * p->n_img;
+  int g = (int)((total + 255) / 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(rpn_keys_kernel, dim3(g), dim3(256), 0, s, p->head, keys, p->n_img, p->Hi * p->Wi, p->A, p->head_c);
+  RpnSelArgs a;
+  a.head = p->head; a.keys = keys; a.n_img = p->n_img; a.Hi = p->Hi; a.Wi = p->Wi; a.A = p->A; a.head_c = p->head_c;
+  a.stride_px = p->stride_px; a.level = p->level; a.kmax = p->kmax; a.slot_off = p->slot_off; a.slots_per_img = p->slots_per_img;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) a.ca[i][j] = p->cell_anchors[i][j];
+  a.clip_x = p->clip_x; a.clip_y = p->clip_y;
+  a.cand_boxes = p->cand_boxes; a.cand_scores = p->cand_scores; a.cand_level = p->cand_level; a.cand_valid = p->cand_valid;
+  const int k = (int)(n < p->kmax ? n : p->kmax);
+  const int n2 = next_pow2(k);
+  hipLaunchKernelGGL(rpn_select_kernel, dim3(p->n_img), dim3(kSelThreads), n2 * 8, s, a);
+  return dp_check_launch("rpn_select_kernel");
+}
+
+extern "C" int64_t dp_nms_workspace_bytes(int n_img, int n_slots) {
+  const long long ncb = (n_slots + 63) / 64;
+  long long off = 0;
+  off = align256(off + (long long)n_img * n_slots * 16);
+  off = align256(off + (long long)n_img * n_slots * 4);
+  off = align256(off + (long long)n_img * n_slots * 4);
+  off = align256(off + (long long)n_img * 4);
+  off = align256(off + (long long)n_img * n_slots * ncb * 8);
+  return off;
+}
+
+extern "C" int dp_batched_nms(const dp_nms_params* p, dp_stream_t stream) {
+  DP_REQUIRE(p, "dp_batched_nms: null params");
+  DP_REQUIRE(p->boxes && p->scores && p->group && p->valid && p->out_boxes && p->out_scores && p->out_index && p->out_count && p->workspace,
+             "dp_batched_nms: null pointer");
+  DP_REQUIRE(p->n_img > 0 && p->n_slots > 0 && p->n_slots <= 8192, "dp_batched_nms: n_slots=%d outside (0, 8192]", p->n_slots);
+  DP_REQUIRE(p->max_out > 0, "dp_batched_nms: max_out");
+  hipStream_t s = as_stream(stream);
+  NmsWs w = carve_nms_ws(p->workspace, p->n_img, p->n_slots);
+  const int n2 = next_pow2(p->n_slots);
+  const int ncb = (p->n_slots + 63) / 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(p->n_img), dim3(kSortThreads), n2 * 8, s, p->boxes, p->scores, p->group, p->valid, p->n_slots, n2,
+                     p->trick_max_numel, w);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb, ncb, p->n_img), dim3(64), 0, s, p->n_slots, ncb, p->iou_thr, w);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(p->n_img), dim3(64), ncb * 8, s, p->boxes, p->scores, p->n_slots, ncb, p->max_out, w, p->out_boxes,
+                     p->out_scores, p->out_index, p->out_count);
+  return dp_check_launch("nms kernels");
+}
+
+extern "C" int dp_roi_align_nhwc(const dp_roi_align_params* p, dp_stream_t stream) {
+  DP_REQUIRE(p, "dp_roi_align_nhwc: null params");
+  DP_REQUIRE(p->boxes && p->counts && p->out, "dp_roi_align_nhwc: null pointer");
+  DP_REQUIRE(p->n_levels == 1 || p->n_levels == 4, "dp_roi_align_nhwc: n_levels=%d", p->n_levels);
+  DP_REQUIRE(p->n_img > 0 && p->max_rois > 0 && p->C > 0 && p->C % 4 == 0 && p->P > 0 && p->sampling > 0, "dp_roi_align_nhwc: bad shape");
+  DP_REQUIRE(!p->compact || p->roi_offsets, "dp_roi_align_nhwc: compact mode needs roi_offsets");
+  RoiArgs a;
+  for (int i = 0; i < 4; ++i) {
+    a.feat[i] = i < p->n_levels ? p->feat[i] : nullptr;
+    a.Hl[i] = p->Hl[i]; a.Wl[i] = p->Wl[i]; a.scale[i] = p->scale[i];
+    if (i < p->n_levels) DP_REQUIRE(a.feat[i] && a.Hl[i] > 0 && a.Wl[i] > 0, "dp_roi_align_nhwc: level %d map", i);
+  }
+  a.n_levels = p->n_levels; a.min_level = p->min_level; a.C = p->C; a.P = p->P; a.sampling = p->sampling;
+  a.boxes = p->boxes; a.counts = p->counts; a.n_img = p->n_img; a.max_rois = p->max_rois; a.out = p->out;
+  a.compact = p->compact; a.roi_offsets = p->roi_offsets;
+  hipStream_t s = as_stream(stream);
+  const dim3 grid(p->P, p->max_rois, p->n_img), block(256);
+  if (p->dtype == DP_F32) hipLaunchKernelGGL(roi_align_kernel<float>, grid, block, 0, s, a);
+  else if (p->dtype == DP_BF16) hipLaunchKernelGGL(roi_align_kernel<uint16_t>, grid, block, 0, s, a);
+  else return dp_fail(DP_ERR_BAD_ARG, "dp_roi_align_nhwc: bad dtype");
+  return dp_check_launch("roi_align_kernel");
+}
+
+extern "C" int dp_box_decode_score(const dp_box_decode_params* p, dp_stream_t stream) {
+  DP_REQUIRE(p, "dp_box_decode_score: null params");
+  DP_REQUIRE(p->logits && p->prop_boxes && p->prop_counts && p->cand_boxes && p->cand_scores && p->cand_group && p->cand_valid,
+             "dp_box_decode_score: null pointer");
+  DP_REQUIRE(p->n_img > 0 && p->max_rois > 0 && p->ld >= 6, "dp_box_decode_score: bad shape");
+  const int total = p->n_img * p->max_rois;
+  hipLaunchKernelGGL(box_decode_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), *p);
+  return dp_check_launch("box_decode_kernel");
+}
+
+extern "C" int dp_postprocess_boxes(const dp_postprocess_params* p, dp_stream_t stream) {
+  DP_REQUIRE(p, "dp_postprocess_boxes: null params");
+  DP_REQUIRE(p->boxes && p->counts && p->scale_xy && p->out_hw && p->out_boxes && p->keep, "dp_postprocess_boxes: null pointer");
+  DP_REQUIRE(p->n_img > 0 && p->max_dets > 0, "dp_postprocess_boxes: bad shape");
+  const int total = p->n_img * p->max_dets;
+  hipLaunchKernelGGL(postprocess_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), *p);
+  return dp_check_launch("postprocess_kernel");
+}

@@ -1,0 +1,374 @@
+// Memory-bound NHWC helper kernels of the DensePose path (HBM-bound: coalesced 8/16-byte accesses,
+// grid-stride, no LDS needed except the GroupNorm reduction).
+#include "dp_common.h"
+
+#pragma clang fp contract(off)  // keep mul/add un-fused: these ops are compared with the CPU oracle
+
+thread_local char dp_err_buf[512] = {0};
+
+extern "C" int dp_abi_version(void) { return DP_ABI_VERSION; }
+extern "C" const char* dp_last_error(void) { return dp_err_buf; }
+
+namespace {
+
+constexpr int kBlock = 256;
+inline int grid_for(long long work) {
+  long long g = (work + kBlock - 1) / kBlock;
+  if (g > 256 * 16) g = 256 * 16;  // ~16 workgroups per CU, grid-stride beyond that
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---- K2 preprocess: planar uint8 [n][3][h][w] -> NHWC8 (x - mean)/std, zero padded ------------------
+template <typename T>
+__global__ void preprocess_kernel(const uint8_t* __restrict__ src, T* __restrict__ dst, int n_img, int h, int w, int Hp,
+                                  int Wp, float m0, float m1, float m2, float s0, float s1, float s2) {
+  const long long total = (long long)n_img * Hp * Wp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wp);
+    const long long t = i / Wp;
+    const int y = (int)(t % Hp);
+    const int n = (int)(t / Hp);
+    float4 lo = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y < h && x < w) {
+      const uint8_t* s = src + ((long long)n * 3 * h + y) * w + x;
+      lo.x = ((float)s[0] - m0) / s0;
+      lo.y = ((float)s[(long long)h * w] - m1) / s1;
+      lo.z = ((float)s[2ll * h * w] - m2) / s2;
+    }
+    T* d = dst + i * 8;
+    store4(d, lo);
+    store4(d + 4, make_float4(0.f, 0.f, 0.f, 0.f));
+  }
+}
+
+// ---- 3x3 stride-2 pad-1 max pool -------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C, int Ho, int Wo) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * Ho * Wo * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int y = ho * 2 - 1 + dy;
+      if ((unsigned)y >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int x = wo * 2 - 1 + dx;
+        if ((unsigned)x >= (unsigned)W) continue;
+        const float4 v = load4(in + (((long long)n * H + y) * W + x) * C + c4 * 4);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    store4(out + i * 4, m);
+  }
+}
+
+template <typename T>
+__global__ void subsample2_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C, int Ho, int Wo) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * Ho * Wo * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    store4(out + i * 4, load4(in + (((long long)n * H + 2 * ho) * W + 2 * wo) * C + c4 * 4));
+  }
+}
+
+// ---- bilinear x2, align_corners=False: out[2i] = .75 in[i] + .25 in[i-1], out[2i+1] = .75 in[i] + .25 in[i+1]
+//      computed exactly as ATen's upsample_bilinear2d: separable weights (1-l, l) with l in {0.25, 0.75, 0}
+__device__ __forceinline__ void bil_src(int o, int n, int& i0, int& i1, float& l) {
+  // src = max((o + 0.5) * 0.5 - 0.5, 0)
+  float s = ((float)o + 0.5f) * 0.5f - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  l = s - (float)i0;
+}
+__device__ __forceinline__ float4 lerp2d(float4 a, float4 b, float4 c, float4 d, float lx, float ly) {
+  // ATen order: h0lambda * (w0lambda * p00 + w1lambda * p01) + h1lambda * (w0lambda * p10 + w1lambda * p11)
+  const float hx = 1.f - lx, hy = 1.f - ly;
+  float4 r;
+  r.x = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
+  r.y = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+  r.z = hy * (hx * a.z + lx * b.z) + ly * (hx * c.z + lx * d.z);
+  r.w = hy * (hx * a.w + lx * b.w) + ly * (hx * c.w + lx * d.w);
+  return r;
+}
+
+template <typename T>
+__global__ void upsample2x_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C, int accumulate) {
+  const int C4 = C >> 2, Ho = 2 * H, Wo = 2 * W;
+  const long long total = (long long)N * Ho * Wo * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int xo = (int)(t % Wo);
+    t /= Wo;
+    const int yo = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bil_src(yo, H, y0, y1, ly);
+    bil_src(xo, W, x0, x1, lx);
+    const T* base = in + (long long)n * H * W * C + c4 * 4;
+    const float4 a = load4(base + ((long long)y0 * W + x0) * C);
+    const float4 b = load4(base + ((long long)y0 * W + x1) * C);
+    const float4 c = load4(base + ((long long)y1 * W + x0) * C);
+    const float4 d = load4(base + ((long long)y1 * W + x1) * C);
+    float4 r = lerp2d(a, b, c, d, lx, ly);
+    if (accumulate) {
+      const float4 o = load4(out + i * 4);
+      r.x = o.x + r.x; r.y = o.y + r.y; r.z = o.z + r.z; r.w = o.w + r.w;
+    }
+    store4(out + i * 4, r);
+  }
+}
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ in, T* __restrict__ out, long long count4) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 a = load4(in + i * 4), o = load4(out + i * 4);
+    store4(out + i * 4, make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w));
+  }
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long long count) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
+    Elem<TO>::store(out + i, Elem<TI>::load(in + i));
+}
+
+// ---- K18: bilinear x2 + channel split + NHWC -> NCHW (fp32) --------------------------------------------
+__global__ void iuv_upsample_split_kernel(const float* __restrict__ in, int R, int Hs, int Ws, int in_c, int n_coarse, int n_fine,
+                                          float* __restrict__ coarse, float* __restrict__ fine, float* __restrict__ u,
+                                          float* __restrict__ v) {
+  // one thread per (r, c, yo, xo) of the OUTPUT so that NCHW stores are coalesced along x
+  const int Ho = 2 * Hs, Wo = 2 * Ws, Ctot = n_coarse + 3 * n_fine;
+  const long long total = (long long)R * Ctot * Ho * Wo;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int xo = (int)(i % Wo);
+    long long t = i / Wo;
+    const int yo = (int)(t % Ho);
+    t /= Ho;
+    const int c = (int)(t % Ctot);
+    const int r = (int)(t / Ctot);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bil_src(yo, Hs, y0, y1, ly);
+    bil_src(xo, Ws, x0, x1, lx);
+    const float* base = in + (long long)r * Hs * Ws * in_c + c;
+    const float a = base[((long long)y0 * Ws + x0) * in_c];
+    const float b = base[((long long)y0 * Ws + x1) * in_c];
+    const float cc = base[((long long)y1 * Ws + x0) * in_c];
+    const float d = base[((long long)y1 * Ws + x1) * in_c];
+    const float hx = 1.f - lx, hy = 1.f - ly;
+    const float val = hy * (hx * a + lx * b) + ly * (hx * cc + lx * d);
+    const long long hw = (long long)Ho * Wo;
+    const long long pix = (long long)yo * Wo + xo;
+    if (c < n_coarse) coarse[((long long)r * n_coarse + c) * hw + pix] = val;
+    else if (c < n_coarse + n_fine) fine[((long long)r * n_fine + (c - n_coarse)) * hw + pix] = val;
+    else if (c < n_coarse + 2 * n_fine) u[((long long)r * n_fine + (c - n_coarse - n_fine)) * hw + pix] = val;
+    else v[((long long)r * n_fine + (c - n_coarse - 2 * n_fine)) * hw + pix] = val;
+  }
+}
+
+// ---- K17: GroupNorm(+ReLU) per ROI, NHWC slice; one workgroup per (roi, group) ------------------------------
+template <typename T>
+__global__ void groupnorm_kernel(T* __restrict__ x, int HW, int C, int c_stride, int c_off, int groups, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float eps, int relu) {
+  const int r = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cg = C / groups;
+  T* base = x + (long long)r * HW * c_stride + c_off + g * cg;
+  const int n = HW * cg;
+  // two-pass (mean, then centred variance) in fp32 with a fixed reduction tree -> deterministic
+  __shared__ float red[kBlock];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += kBlock) s += Elem<T>::load(base + (long long)(i / cg) * c_stride + (i % cg));
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float mean = red[0] / (float)n;
+  __syncthreads();
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+    const float d = Elem<T>::load(base + (long long)(i / cg) * c_stride + (i % cg)) - mean;
+    q += d * d;
+  }
+  red[threadIdx.x] = q;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float rstd = 1.0f / sqrtf(red[0] / (float)n + eps);
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+    const int c = i % cg;
+    T* p = base + (long long)(i / cg) * c_stride + c;
+    float v = (Elem<T>::load(p) - mean) * rstd * gamma[g * cg + c] + beta[g * cg + c];
+    if (relu) v = fmaxf(v, 0.f);
+    Elem<T>::store(p, v);
+  }
+}
+
+template <typename T>
+__global__ void gap_kernel(const T* __restrict__ in, T* __restrict__ out, int HW, int C) {
+  // one workgroup per roi; thread t owns channels t, t+256, ... ; sequential sum over pixels (fixed order)
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    const T* p = in + (long long)r * HW * C + c;
+    for (int i = 0; i < HW; ++i) s += Elem<T>::load(p + (long long)i * C);
+    Elem<T>::store(out + (long long)r * C + c, s / (float)HW);
+  }
+}
+
+template <typename T>
+__global__ void broadcast_hw_kernel(const T* __restrict__ in, T* __restrict__ out, int R, int HW, int C, int ocs, int oco) {
+  const int C4 = C >> 2;
+  const long long total = (long long)R * HW * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const long long t = i / C4;
+    const int r = (int)(t / HW);
+    store4(out + t * ocs + oco + c4 * 4, load4(in + (long long)r * C + c4 * 4));
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_DTYPE(dtype, KERNEL_CALL_F32, KERNEL_CALL_BF16)                 \
+  if ((dtype) == DP_F32) { KERNEL_CALL_F32; } else if ((dtype) == DP_BF16) { KERNEL_CALL_BF16; } \
+  else return dp_fail(DP_ERR_BAD_ARG, "bad dtype %d", (int)(dtype));
+
+extern "C" int dp_preprocess_u8(const dp_preprocess_params* p, dp_stream_t stream) {
+  DP_REQUIRE(p && p->src && p->dst, "dp_preprocess_u8: null pointer");
+  DP_REQUIRE(p->n_img > 0 && p->h > 0 && p->w > 0 && p->Hp >= p->h && p->Wp >= p->w, "dp_preprocess_u8: bad shape");
+  const long long total = (long long)p->n_img * p->Hp * p->Wp;
+  hipStream_t s = as_stream(stream);
+  DISPATCH_DTYPE(p->dtype,
+                 hipLaunchKernelGGL(preprocess_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, p->src, (float*)p->dst,
+                                    p->n_img, p->h, p->w, p->Hp, p->Wp, p->mean[0], p->mean[1], p->mean[2], p->std[0], p->std[1], p->std[2]),
+                 hipLaunchKernelGGL(preprocess_kernel<uint16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, p->src, (uint16_t*)p->dst,
+                                    p->n_img, p->h, p->w, p->Hp, p->Wp, p->mean[0], p->mean[1], p->mean[2], p->std[0], p->std[1], p->std[2]));
+  return dp_check_launch("preprocess_kernel");
+}
+
+extern "C" int dp_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, dp_stream_t stream) {
+  DP_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dp_maxpool3x3s2_nhwc: bad args");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_DTYPE(dtype,
+                 hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const float*)in, (float*)out, N, H, W, C, Ho, Wo),
+                 hipLaunchKernelGGL(maxpool3x3s2_kernel<uint16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const uint16_t*)in, (uint16_t*)out, N, H, W, C, Ho, Wo));
+  return dp_check_launch("maxpool3x3s2_kernel");
+}
+
+extern "C" int dp_subsample2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, dp_stream_t stream) {
+  DP_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dp_subsample2_nhwc: bad args");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_DTYPE(dtype,
+                 hipLaunchKernelGGL(subsample2_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const float*)in, (float*)out, N, H, W, C, Ho, Wo),
+                 hipLaunchKernelGGL(subsample2_kernel<uint16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const uint16_t*)in, (uint16_t*)out, N, H, W, C, Ho, Wo));
+  return dp_check_launch("subsample2_kernel");
+}
+
+extern "C" int dp_upsample_bilinear2x_nhwc(const void* in, void* out, int N, int H, int W, int C, int accumulate, int dtype,
+                                           dp_stream_t stream) {
+  DP_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dp_upsample_bilinear2x_nhwc: bad args");
+  const long long total = (long long)N * 4 * H * W * (C / 4);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_DTYPE(dtype,
+                 hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const float*)in, (float*)out, N, H, W, C, accumulate),
+                 hipLaunchKernelGGL(upsample2x_kernel<uint16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const uint16_t*)in, (uint16_t*)out, N, H, W, C, accumulate));
+  return dp_check_launch("upsample2x_kernel");
+}
+
+extern "C" int dp_add_nhwc(const void* in, void* out, int64_t count, int dtype, dp_stream_t stream) {
+  DP_REQUIRE(in && out && count >= 0 && count % 4 == 0, "dp_add_nhwc: bad args");
+  if (count == 0) return DP_OK;
+  hipStream_t s = as_stream(stream);
+  DISPATCH_DTYPE(dtype,
+                 hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(count / 4)), dim3(kBlock), 0, s, (const float*)in, (float*)out, (long long)count / 4),
+                 hipLaunchKernelGGL(add_kernel<uint16_t>, dim3(grid_for(count / 4)), dim3(kBlock), 0, s, (const uint16_t*)in, (uint16_t*)out, (long long)count / 4));
+  return dp_check_launch("add_kernel");
+}
+
+extern "C" int dp_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t count, dp_stream_t stream) {
+  DP_REQUIRE(in && out && count >= 0, "dp_cast: bad args");
+  if (count == 0) return DP_OK;
+  hipStream_t s = as_stream(stream);
+  const dim3 g(grid_for(count)), b(kBlock);
+  if (in_dtype == DP_F32 && out_dtype == DP_BF16) hipLaunchKernelGGL((cast_kernel<float, uint16_t>), g, b, 0, s, (const float*)in, (uint16_t*)out, (long long)count);
+  else if (in_dtype == DP_BF16 && out_dtype == DP_F32) hipLaunchKernelGGL((cast_kernel<uint16_t, float>), g, b, 0, s, (const uint16_t*)in, (float*)out, (long long)count);
+  else if (in_dtype == DP_F32 && out_dtype == DP_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)in, (float*)out, (long long)count);
+  else if (in_dtype == DP_BF16 && out_dtype == DP_BF16) hipLaunchKernelGGL((cast_kernel<uint16_t, uint16_t>), g, b, 0, s, (const uint16_t*)in, (uint16_t*)out, (long long)count);
+  else return dp_fail(DP_ERR_BAD_ARG, "dp_cast: bad dtypes %d -> %d", in_dtype, out_dtype);
+  return dp_check_launch("cast_kernel");
+}
+
+extern "C" int dp_iuv_upsample_split(const dp_iuv_params* p, dp_stream_t stream) {
+  DP_REQUIRE(p, "dp_iuv_upsample_split: null params");
+  if (p->R == 0) return DP_OK;
+  DP_REQUIRE(p->in && p->coarse && p->fine && p->u && p->v, "dp_iuv_upsample_split: null pointer");
+  DP_REQUIRE(p->R > 0 && p->Hs > 0 && p->Ws > 0 && p->n_coarse > 0 && p->n_fine > 0 && p->in_c >= p->n_coarse + 3 * p->n_fine,
+             "dp_iuv_upsample_split: bad shape");
+  const long long total = (long long)p->R * (p->n_coarse + 3 * p->n_fine) * 4 * p->Hs * p->Ws;
+  hipLaunchKernelGGL(iuv_upsample_split_kernel, dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), p->in, p->R, p->Hs, p->Ws,
+                     p->in_c, p->n_coarse, p->n_fine, p->coarse, p->fine, p->u, p->v);
+  return dp_check_launch("iuv_upsample_split_kernel");
+}
+
+extern "C" int dp_groupnorm_relu_nhwc(const dp_groupnorm_params* p, dp_stream_t stream) {
+  DP_REQUIRE(p, "dp_groupnorm_relu_nhwc: null params");
+  if (p->R == 0) return DP_OK;
+  DP_REQUIRE(p->x && p->gamma && p->beta && p->R > 0 && p->HW > 0 && p->groups > 0 && p->C % p->groups == 0 &&
+                 p->c_off >= 0 && p->c_off + p->C <= p->c_stride,
+             "dp_groupnorm_relu_nhwc: bad args");
+  hipStream_t s = as_stream(stream);
+  const dim3 g(p->R * p->groups), b(kBlock);
+  DISPATCH_DTYPE(p->dtype,
+                 hipLaunchKernelGGL(groupnorm_kernel<float>, g, b, 0, s, (float*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu),
+                 hipLaunchKernelGGL(groupnorm_kernel<uint16_t>, g, b, 0, s, (uint16_t*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu));
+  return dp_check_launch("groupnorm_kernel");
+}
+
+extern "C" int dp_global_avgpool_nhwc(const void* in, void* out, int R, int HW, int C, int dtype, dp_stream_t stream) {
+  if (R == 0) return DP_OK;
+  DP_REQUIRE(in && out && R > 0 && HW > 0 && C > 0, "dp_global_avgpool_nhwc: bad args");
+  hipStream_t s = as_stream(stream);
+  DISPATCH_DTYPE(dtype,
+                 hipLaunchKernelGGL(gap_kernel<float>, dim3(R), dim3(kBlock), 0, s, (const float*)in, (float*)out, HW, C),
+                 hipLaunchKernelGGL(gap_kernel<uint16_t>, dim3(R), dim3(kBlock), 0, s, (const uint16_t*)in, (uint16_t*)out, HW, C));
+  return dp_check_launch("gap_kernel");
+}
+
+extern "C" int dp_broadcast_hw_nhwc(const void* in, void* out, int R, int HW, int C, int out_c_stride, int out_c_off, int dtype,
+                                    dp_stream_t stream) {
+  if (R == 0) return DP_OK;
+  DP_REQUIRE(in && out && R > 0 && HW > 0 && C > 0 && C % 4 == 0 && out_c_off % 4 == 0 && out_c_off + C <= out_c_stride,
+             "dp_broadcast_hw_nhwc: bad args");
+  const long long total = (long long)R * HW * (C / 4);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_DTYPE(dtype,
+                 hipLaunchKernelGGL(broadcast_hw_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const float*)in, (float*)out, R, HW, C, out_c_stride, out_c_off),
+                 hipLaunchKernelGGL(broadcast_hw_kernel<uint16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const uint16_t*)in, (uint16_t*)out, R, HW, C, out_c_stride, out_c_off));
+  return dp_check_launch("broadcast_hw_kernel");
+}

@@ -1,0 +1,432 @@
+"""MI355X DensePose inference engine: orchestrates the C-ABI HIP kernels over a batch of equal-size frames.
+
+Mirrors ``GeneralizedRCNN.inference`` (/root/reference/detectron2/modeling/meta_arch/rcnn.py:110-154) stage
+by stage; every arithmetic step is a call into libdensepose_hip.so (no torch compute ops on the hot path -
+torch only owns device memory and the stream). Batch semantics follow SURVEY Q6: a batch of N frames
+equals N independent single-image calls (per-image top-k / NMS / padding).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .pack import PackedModel, round_up
+from .weights import decoder_layout, resnet_blocks
+
+FPN_STRIDES = (4, 8, 16, 32, 64)
+CPU_TRICK_MAX_NUMEL = 4000  # torchvision batched_nms strategy switch on the reference's CPU path
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class Act:
+    """NHWC activation living in a torch allocation."""
+    __slots__ = ("t", "N", "H", "W", "C")
+
+    def __init__(self, t, N, H, W, C):
+        self.t, self.N, self.H, self.W, self.C = t, N, H, W, C
+
+
+class Engine:
+    def __init__(self, cfg, state, dtype="bf16", device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise L.DensePoseHipError("no GPU visible: the DensePose engine has no CPU fallback")
+        self.lib = L.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.dt = L.DP_BF16 if dtype in ("bf16", "bfloat16") else L.DP_F32
+        self.tdt = torch.bfloat16 if self.dt == L.DP_BF16 else torch.float32
+        self.model = PackedModel(cfg, state, self.dt, self.device)
+        self.cell_anchors = []
+        for size in cfg.anchor_sizes:  # anchor_generator.py:181-216 (python float64, then fp32)
+            rows = []
+            for r in cfg.anchor_ratios:
+                w = math.sqrt(size ** 2.0 / r)
+                h = r * w
+                rows.append([np.float32(-w / 2.0), np.float32(-h / 2.0), np.float32(w / 2.0), np.float32(h / 2.0)])
+            self.cell_anchors.append(rows)
+        self.stage_ms = {}
+        self.keep_intermediates = False
+        self.inter = {}
+        self.flops_last = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _empty(self, shape, dtype=None):
+        return torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
+
+    def conv(self, layer, x, relu=False, residual=None, rshift=0, out_f32=False, out=None, out_c_stride=None, out_c_off=0,
+             out_geom=None):
+        """x: Act. Returns Act. out_geom: (Ho, Wo, osN, osH, osW, base_elems) override for the sub-pixel deconv."""
+        p = L.ConvParams()
+        N, H, W = x.N, x.H, x.W
+        assert x.C == layer.cin, (layer.name, x.C, layer.cin)
+        s = layer.stride
+        if s == 1:
+            Ho, Wo = H, W
+        else:
+            # every strided conv of this model has pad = (k-1)/2 -> Ho = floor((H - 1) / s) + 1
+            Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        cs = out_c_stride or layer.cout
+        odt = torch.float32 if out_f32 else self.tdt
+        if out is None:
+            out = self._empty((N, Ho, Wo, cs), odt)
+        p.in_, p.weight, p.ktab, p.bias = x.t.data_ptr(), layer.weight.data_ptr(), layer.ktab.data_ptr(), layer.bias.data_ptr()
+        p.residual = residual.t.data_ptr() if residual is not None else None
+        es_out = out.element_size()
+        if out_geom is None:
+            p.out = out.data_ptr() + out_c_off * es_out
+            p.osN, p.osH, p.osW = Ho * Wo * cs, Wo * cs, cs
+        else:
+            osN, osH, osW, base = out_geom
+            p.out = out.data_ptr() + base * es_out
+            p.osN, p.osH, p.osW = osN, osH, osW
+        p.N, p.H, p.W, p.Cin = N, H, W, x.C
+        p.Ho, p.Wo, p.Cout = Ho, Wo, layer.cout
+        p.Cout_w, p.Kpad = layer.cout_w, layer.kpad
+        p.stride = s
+        if residual is not None:
+            p.rsN, p.rsH, p.rsW = residual.H * residual.W * residual.C, residual.W * residual.C, residual.C
+            assert residual.C == layer.cout
+        p.rshift = rshift
+        p.relu = 1 if relu else 0
+        p.dtype = self.dt
+        p.out_f32 = 1 if out_f32 else 0
+        p.hi_off, p.wi_off = layer.hi_off, layer.wi_off
+        L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
+        self.flops_last += 2 * layer.macs_per_pixel * N * Ho * Wo
+        return Act(out, N, Ho, Wo, cs)
+
+    # ------------------------------------------------------------------ stages
+    def preprocess(self, images_u8, Hp, Wp):
+        n, _, h, w = images_u8.shape
+        out = self._empty((n, Hp, Wp, 8))
+        p = L.PreprocessParams()
+        p.src, p.dst = images_u8.data_ptr(), out.data_ptr()
+        p.n_img, p.h, p.w, p.Hp, p.Wp, p.dtype = n, h, w, Hp, Wp, self.dt
+        for i in range(3):
+            p.mean[i] = self.cfg.pixel_mean[i]
+            p.std[i] = self.cfg.pixel_std[i]
+        L.check(self.lib.dp_preprocess_u8(C.byref(p), self._stream()), "dp_preprocess_u8")
+        return Act(out, n, Hp, Wp, 8)
+
+    def backbone(self, x):
+        Ls = self.model.layers
+        cfg = self.cfg
+        bu = "backbone.bottom_up."
+        x = self.conv(Ls["stem"], x, relu=True)
+        Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
+        pooled = self._empty((x.N, Ho, Wo, x.C))
+        L.check(self.lib.dp_maxpool3x3s2_nhwc(x.t.data_ptr(), pooled.data_ptr(), x.N, x.H, x.W, x.C, self.dt, self._stream()), "maxpool")
+        x = Act(pooled, x.N, Ho, Wo, x.C)
+        res = {}
+        for stage, b, cin, cmid, cout, stride, sc in resnet_blocks(cfg):
+            p = "%s%s.%d." % (bu, stage, b)
+            shortcut = self.conv(Ls[p + "shortcut"], x) if sc else x
+            t = self.conv(Ls[p + "conv1"], x, relu=True)
+            t = self.conv(Ls[p + "conv2"], t, relu=True)
+            x = self.conv(Ls[p + "conv3"], t, relu=True, residual=shortcut)
+            res[stage] = x
+        feats = {}
+        prev = self.conv(Ls["fpn_lateral5"], res["res5"])
+        feats["p5"] = self.conv(Ls["fpn_output5"], prev)
+        for lvl in (4, 3, 2):
+            prev = self.conv(Ls["fpn_lateral%d" % lvl], res["res%d" % lvl], residual=prev, rshift=1)  # + nearest x2 of top-down
+            feats["p%d" % lvl] = self.conv(Ls["fpn_output%d" % lvl], prev)
+        p5 = feats["p5"]
+        H6, W6 = (p5.H - 1) // 2 + 1, (p5.W - 1) // 2 + 1
+        p6 = self._empty((p5.N, H6, W6, p5.C))
+        L.check(self.lib.dp_subsample2_nhwc(p5.t.data_ptr(), p6.data_ptr(), p5.N, p5.H, p5.W, p5.C, self.dt, self._stream()), "subsample2")
+        feats["p6"] = Act(p6, p5.N, H6, W6, p5.C)
+        return feats
+
+    def rpn(self, feats, Hp, Wp):
+        cfg = self.cfg
+        Ls = self.model.layers
+        n = feats["p2"].N
+        kmax = cfg.rpn_pre_topk
+        nl = 5
+        slots = nl * kmax
+        cand_boxes = self._empty((n, slots, 4), torch.float32)
+        cand_scores = self._empty((n, slots), torch.float32)
+        cand_level = self._empty((n, slots), torch.int32)
+        cand_valid = self._empty((n, slots), torch.int32)
+        A = len(cfg.anchor_ratios)
+        ws_bytes = max(self.lib.dp_rpn_topk_workspace_bytes(n, feats[k].H, feats[k].W, A) for k in ("p2", "p3", "p4", "p5", "p6"))
+        ws = self._empty((ws_bytes,), torch.uint8)
+        heads = []
+        for li, k in enumerate(("p2", "p3", "p4", "p5", "p6")):
+            f = feats[k]
+            t = self.conv(Ls["rpn_conv"], f, relu=True)
+            head = self.conv(Ls["rpn_head"], t, out_f32=True)
+            heads.append(head)
+            p = L.RpnLevelParams()
+            p.head = head.t.data_ptr()
+            p.n_img, p.Hi, p.Wi, p.A, p.head_c = n, f.H, f.W, A, head.C
+            p.stride_px = FPN_STRIDES[li]
+            for a in range(A):
+                for c in range(4):
+                    p.cell_anchors[a][c] = self.cell_anchors[li][a][c]
+            p.level, p.kmax, p.slot_off, p.slots_per_img = li, kmax, li * kmax, slots
+            p.clip_x, p.clip_y = float(Hp), float(Wp)  # Q1: x clipped to the padded HEIGHT, y to the padded WIDTH
+            p.cand_boxes, p.cand_scores = cand_boxes.data_ptr(), cand_scores.data_ptr()
+            p.cand_level, p.cand_valid = cand_level.data_ptr(), cand_valid.data_ptr()
+            p.workspace = ws.data_ptr()
+            L.check(self.lib.dp_rpn_topk_decode(C.byref(p), self._stream()), "dp_rpn_topk_decode")
+        post = cfg.rpn_post_topk
+        props, scores, _, counts = self.nms(cand_boxes, cand_scores, cand_level, cand_valid, n, slots, cfg.rpn_nms_thresh, post)
+        if self.keep_intermediates:
+            self.inter["rpn_heads"] = heads
+            self.inter["cand"] = (cand_boxes, cand_scores, cand_level, cand_valid)
+        return props, scores, counts
+
+    def nms(self, boxes, scores, group, valid, n, slots, thr, max_out):
+        out_boxes = self._empty((n, max_out, 4), torch.float32)
+        out_scores = self._empty((n, max_out), torch.float32)
+        out_index = self._empty((n, max_out), torch.int32)
+        out_count = self._empty((n,), torch.int32)
+        ws = self._empty((self.lib.dp_nms_workspace_bytes(n, slots),), torch.uint8)
+        p = L.NmsParams()
+        p.boxes, p.scores, p.group, p.valid = boxes.data_ptr(), scores.data_ptr(), group.data_ptr(), valid.data_ptr()
+        p.n_img, p.n_slots, p.iou_thr, p.max_out, p.trick_max_numel = n, slots, thr, max_out, CPU_TRICK_MAX_NUMEL
+        p.out_boxes, p.out_scores, p.out_index, p.out_count = out_boxes.data_ptr(), out_scores.data_ptr(), out_index.data_ptr(), out_count.data_ptr()
+        p.workspace = ws.data_ptr()
+        L.check(self.lib.dp_batched_nms(C.byref(p), self._stream()), "dp_batched_nms")
+        return out_boxes, out_scores, out_index, out_count
+
+    def roi_align(self, maps, scales, boxes, counts, n, max_rois, P, sampling, out, compact=False, offsets=None):
+        p = L.RoiAlignParams()
+        for i, m in enumerate(maps):
+            p.feat[i] = m.t.data_ptr()
+            p.Hl[i], p.Wl[i], p.scale[i] = m.H, m.W, scales[i]
+        p.n_levels, p.min_level = len(maps), 2
+        p.C, p.P, p.sampling = maps[0].C, P, sampling
+        p.boxes, p.counts, p.n_img, p.max_rois = boxes.data_ptr(), counts.data_ptr(), n, max_rois
+        p.out, p.dtype = out.data_ptr(), self.dt
+        p.compact = 1 if compact else 0
+        p.roi_offsets = offsets.data_ptr() if offsets is not None else None
+        L.check(self.lib.dp_roi_align_nhwc(C.byref(p), self._stream()), "dp_roi_align_nhwc")
+
+    def box_branch(self, feats, props, counts):
+        cfg = self.cfg
+        Ls = self.model.layers
+        n = feats["p2"].N
+        R = cfg.rpn_post_topk
+        P = cfg.box_pool
+        maps = [feats[k] for k in ("p2", "p3", "p4", "p5")]
+        Cc = maps[0].C
+        pooled = torch.zeros((n * R, P, P, Cc), dtype=self.tdt, device=self.device)  # rows >= count stay 0 (finite)
+        self.roi_align(maps, [1.0 / s for s in FPN_STRIDES[:4]], props, counts, n, R, P, cfg.box_sampling, pooled)
+        x = Act(pooled.view(n * R, 1, 1, P * P * Cc), n * R, 1, 1, P * P * Cc)
+        x = self.conv(Ls["fc1"], x, relu=True)
+        for i in range(1, cfg.box_num_fc):
+            x = self.conv(Ls["fc%d" % (i + 1)], x, relu=True)
+        logits = self.conv(Ls["box_out"], x, out_f32=True)
+        cand_boxes = self._empty((n, R, 4), torch.float32)
+        cand_scores = self._empty((n, R), torch.float32)
+        cand_group = self._empty((n, R), torch.int32)
+        cand_valid = self._empty((n, R), torch.int32)
+        p = L.BoxDecodeParams()
+        p.logits, p.ld = logits.t.data_ptr(), logits.C
+        p.prop_boxes, p.prop_counts, p.n_img, p.max_rois = props.data_ptr(), counts.data_ptr(), n, R
+        p.wx, p.wy, p.ww, p.wh = cfg.bbox_reg_weights
+        p.score_thresh = cfg.score_thresh
+        p.cand_boxes, p.cand_scores, p.cand_group, p.cand_valid = (cand_boxes.data_ptr(), cand_scores.data_ptr(),
+                                                                   cand_group.data_ptr(), cand_valid.data_ptr())
+        L.check(self.lib.dp_box_decode_score(C.byref(p), self._stream()), "dp_box_decode_score")
+        D = max(cfg.dets_per_image, 1)
+        det_boxes, det_scores, det_index, det_counts = self.nms(cand_boxes, cand_scores, cand_group, cand_valid, n, R, cfg.nms_thresh, D)
+        if self.keep_intermediates:
+            self.inter["box_pooled"] = pooled
+            self.inter["box_logits"] = logits
+        return det_boxes, det_scores, det_counts
+
+    def decoder(self, feats):
+        Ls = self.model.layers
+        acc = None
+        for lvl, nconv in decoder_layout(self.cfg):
+            t = feats[lvl]
+            for k in range(nconv):
+                t = self.conv(Ls["roi_heads.decoder.%s.%d" % (lvl, 2 * k)], t, relu=True)
+                if lvl == "p2":
+                    acc = t
+                    continue
+                last = (k == nconv - 1)
+                if last:
+                    assert 2 * t.H == acc.H and 2 * t.W == acc.W and t.C == acc.C
+                    L.check(self.lib.dp_upsample_bilinear2x_nhwc(t.t.data_ptr(), acc.t.data_ptr(), t.N, t.H, t.W, t.C, 1, self.dt,
+                                                                 self._stream()), "upsample+add")
+                else:
+                    up = self._empty((t.N, 2 * t.H, 2 * t.W, t.C))
+                    L.check(self.lib.dp_upsample_bilinear2x_nhwc(t.t.data_ptr(), up.data_ptr(), t.N, t.H, t.W, t.C, 0, self.dt,
+                                                                 self._stream()), "upsample")
+                    t = Act(up, t.N, 2 * t.H, 2 * t.W, t.C)
+        return self.conv(Ls["decoder_predictor"], acc)
+
+    def groupnorm(self, x_t, R, HW, Cc, c_stride, c_off, gn, relu=True):
+        p = L.GroupNormParams()
+        p.x, p.R, p.HW, p.C, p.c_stride, p.c_off, p.groups = x_t.data_ptr(), R, HW, Cc, c_stride, c_off, 32
+        p.gamma, p.beta, p.eps, p.relu, p.dtype = gn[0].data_ptr(), gn[1].data_ptr(), 1e-5, 1 if relu else 0, self.dt
+        L.check(self.lib.dp_groupnorm_relu_nhwc(C.byref(p), self._stream()), "dp_groupnorm_relu_nhwc")
+
+    def dp_head(self, x):
+        cfg = self.cfg
+        Ls = self.model.layers
+        R, P = x.N, x.H
+        if cfg.is_deeplab:
+            gn = self.model.gn
+            Cc = x.C
+            cat = self._empty((R, P, P, 5 * Cc))
+            for i in range(4):
+                self.conv(Ls["aspp%d" % i], x, out=cat, out_c_stride=5 * Cc, out_c_off=i * Cc)
+                self.groupnorm(cat, R, P * P, Cc, 5 * Cc, i * Cc, gn["aspp%d" % i])
+            pooled = self._empty((R, 1, 1, Cc))
+            L.check(self.lib.dp_global_avgpool_nhwc(x.t.data_ptr(), pooled.data_ptr(), R, P * P, Cc, self.dt, self._stream()), "gap")
+            t = self.conv(Ls["aspp4"], Act(pooled, R, 1, 1, Cc))
+            self.groupnorm(t.t, R, 1, Cc, Cc, 0, gn["aspp4"])
+            L.check(self.lib.dp_broadcast_hw_nhwc(t.t.data_ptr(), cat.data_ptr(), R, P * P, Cc, 5 * Cc, 4 * Cc, self.dt, self._stream()),
+                    "broadcast")
+            x = self.conv(Ls["aspp_project"], Act(cat, R, P, P, 5 * Cc), relu=True)
+        for i in range(cfg.dp_num_convs):
+            if cfg.is_deeplab:
+                x = self.conv(Ls["dp_fcn%d" % (i + 1)], x)
+                self.groupnorm(x.t, R, P * P, x.C, x.C, 0, self.model.gn["dp_fcn%d" % (i + 1)])
+            else:
+                x = self.conv(Ls["dp_fcn%d" % (i + 1)], x, relu=True)
+        return x
+
+    def dp_predictor(self, x):
+        cfg = self.cfg
+        R, P = x.N, x.H
+        Ci = self.model.iuv_c
+        P2 = 2 * P
+        low = self._empty((R, P2, P2, Ci), torch.float32)
+        for (a, b), layer in self.model.deconv.items():
+            # sub-pixel scatter: output pixel (2i + a, 2j + b)
+            self.conv(layer, x, out_f32=True, out=low, out_c_stride=Ci,
+                      out_geom=(P2 * P2 * Ci, 2 * P2 * Ci, 2 * Ci, (a * P2 + b) * Ci))
+        S = 2 * P2
+        nc, nf = cfg.dp_coarse_ch, cfg.dp_patches + 1
+        coarse = self._empty((R, nc, S, S), torch.float32)
+        fine = self._empty((R, nf, S, S), torch.float32)
+        u = self._empty((R, nf, S, S), torch.float32)
+        v = self._empty((R, nf, S, S), torch.float32)
+        p = L.IuvParams()
+        p.in_, p.R, p.Hs, p.Ws, p.in_c, p.n_coarse, p.n_fine = low.data_ptr(), R, P2, P2, Ci, nc, nf
+        p.coarse, p.fine, p.u, p.v = coarse.data_ptr(), fine.data_ptr(), u.data_ptr(), v.data_ptr()
+        L.check(self.lib.dp_iuv_upsample_split(C.byref(p), self._stream()), "dp_iuv_upsample_split")
+        return coarse, fine, u, v
+
+    def densepose_branch(self, feats, det_boxes, det_counts_dev, counts_host):
+        cfg = self.cfg
+        n = feats["p2"].N
+        D = det_boxes.shape[1]
+        R = int(sum(counts_host))
+        offs = np.zeros((n,), dtype=np.int32)
+        offs[1:] = np.cumsum(counts_host)[:-1]
+        offsets = torch.from_numpy(offs).to(self.device, non_blocking=True)
+        if cfg.dp_decoder_on:
+            dec = self.decoder(feats)
+            maps, scales = [dec], [1.0 / 4]
+            if self.keep_intermediates:
+                self.inter["decoder_out"] = dec
+        else:
+            maps, scales = [feats[k] for k in ("p2", "p3", "p4", "p5")], [1.0 / s for s in FPN_STRIDES[:4]]
+        P = cfg.dp_pool
+        Cc = maps[0].C
+        pooled = self._empty((max(R, 1), P, P, Cc))
+        if R > 0:
+            self.roi_align(maps, scales, det_boxes, det_counts_dev, n, D, P, cfg.dp_sampling, pooled, compact=True, offsets=offsets)
+        x = Act(pooled[:R], R, P, P, Cc)
+        if R == 0:
+            S = 4 * P
+            z = lambda c: torch.zeros((0, c, S, S), dtype=torch.float32, device=self.device)  # noqa: E731
+            return z(cfg.dp_coarse_ch), z(cfg.dp_patches + 1), z(cfg.dp_patches + 1), z(cfg.dp_patches + 1), offs
+        head = self.dp_head(x)
+        if self.keep_intermediates:
+            self.inter["dp_pooled"] = x
+            self.inter["dp_head_out"] = head
+        coarse, fine, u, v = self.dp_predictor(head)
+        return coarse, fine, u, v, offs
+
+    # ------------------------------------------------------------------ whole path for a batch of equal-size frames
+    @torch.no_grad()
+    def forward_batch(self, images_u8, orig_hw, given_boxes=None):
+        """images_u8: uint8 [n,3,h,w] on the device (already resized, defaults.py:89). orig_hw: list of (H, W).
+        Returns a list of n dicts with the reference's 8 keys (postprocessing.py:52-61)."""
+        cfg = self.cfg
+        assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[1] == 3
+        images_u8 = images_u8.contiguous()
+        n, _, h, w = images_u8.shape
+        Hp, Wp = round_up(h, 32), round_up(w, 32)
+        self.flops_last = 0
+        self.inter = {}
+        x = self.preprocess(images_u8, Hp, Wp)
+        feats = self.backbone(x)
+        if self.keep_intermediates:
+            self.inter.update(feats)
+        if given_boxes is None:
+            props, prop_scores, prop_counts = self.rpn(feats, Hp, Wp)
+            if self.keep_intermediates:
+                self.inter["proposals"] = (props, prop_scores, prop_counts)
+            det_boxes, det_scores, det_counts = self.box_branch(feats, props, prop_counts)
+        else:
+            det_boxes, det_scores, det_counts = given_boxes
+        counts_host = det_counts.cpu().numpy().astype(np.int64)  # the one host sync of the path: R sizes the head launches
+        coarse, fine, u, v, offs = self.densepose_branch(feats, det_boxes, det_counts, counts_host)
+        # detector_postprocess (postprocessing.py:43-54); image_size there is [W_pad, H_pad] (Q1) minus the padding
+        D = det_boxes.shape[1]
+        scale_xy = np.zeros((n, 2), dtype=np.float32)
+        out_hw = np.zeros((n, 2), dtype=np.float32)
+        for i, (H0, W0) in enumerate(orig_hw):
+            scale_xy[i, 0] = np.float32(W0) / np.float32(w)
+            scale_xy[i, 1] = np.float32(H0) / np.float32(h)
+            out_hw[i] = (H0, W0)
+        scale_d = torch.from_numpy(scale_xy).to(self.device)
+        hw_d = torch.from_numpy(out_hw).to(self.device)
+        fin_boxes = self._empty((n, D, 4), torch.float32)
+        keep = self._empty((n, D), torch.int32)
+        p = L.PostprocessParams()
+        p.boxes, p.counts, p.n_img, p.max_dets = det_boxes.data_ptr(), det_counts.data_ptr(), n, D
+        p.scale_xy, p.out_hw, p.out_boxes, p.keep = scale_d.data_ptr(), hw_d.data_ptr(), fin_boxes.data_ptr(), keep.data_ptr()
+        L.check(self.lib.dp_postprocess_boxes(C.byref(p), self._stream()), "dp_postprocess_boxes")
+        results = []
+        keep_h = None
+        for i in range(n):
+            r = int(counts_host[i])
+            o = int(offs[i])
+            res = {
+                "image_size": torch.tensor([orig_hw[i][0], orig_hw[i][1]], dtype=torch.int64),
+                "pred_boxes": fin_boxes[i, :r],
+                "scores": det_scores[i, :r],
+                "pred_classes": torch.zeros((r,), dtype=torch.int64, device=self.device),
+                "pred_densepose_coarse_segm": coarse[o:o + r],
+                "pred_densepose_fine_segm": fine[o:o + r],
+                "pred_densepose_u": u[o:o + r],
+                "pred_densepose_v": v[o:o + r],
+            }
+            results.append(res)
+        # nonempty filter of postprocessing.py:51 (w >= 0 & h >= 0): always true for decoded boxes; verify lazily
+        self._pending_keep = (keep, counts_host)
+        return results
+
+    def apply_keep_filter(self, results):
+        """Drops detections whose rescaled box has negative extent (cannot happen for finite decoded boxes; kept for
+        bug-compatibility with postprocessing.py:51). Costs one extra sync, so callers may skip it."""
+        keep, counts_host = self._pending_keep
+        kh = keep.cpu().numpy()
+        for i, res in enumerate(results):
+            r = int(counts_host[i])
+            k = kh[i, :r].astype(bool)
+            if not k.all():
+                idx = torch.from_numpy(np.nonzero(k)[0]).to(self.device)
+                for key in list(res):
+                    if key != "image_size":
+                        res[key] = res[key][idx]
+        return results

@@ -1,0 +1,163 @@
+"""ctypes binding of the C-ABI library (include/densepose_hip.h -> libdensepose_hip.so).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdensepose_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+DP_F32, DP_BF16 = 0, 1
+
+c_void_p, c_int, c_i32, c_i64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
+
+
+class PreprocessParams(C.Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p),
+                ("n_img", c_i32), ("h", c_i32), ("w", c_i32), ("Hp", c_i32), ("Wp", c_i32), ("dtype", c_i32),
+                ("mean", c_float * 3), ("inv_std_unused", c_float * 3), ("std", c_float * 3)]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [("in_", c_void_p), ("weight", c_void_p), ("ktab", c_void_p), ("bias", c_void_p),
+                ("residual", c_void_p), ("out", c_void_p),
+                ("N", c_i32), ("H", c_i32), ("W", c_i32), ("Cin", c_i32),
+                ("Ho", c_i32), ("Wo", c_i32), ("Cout", c_i32),
+                ("Cout_w", c_i32), ("Kpad", c_i32),
+                ("stride", c_i32), ("pad_unused", c_i32),
+                ("osN", c_i64), ("osH", c_i64), ("osW", c_i64),
+                ("rsN", c_i64), ("rsH", c_i64), ("rsW", c_i64),
+                ("rshift", c_i32), ("relu", c_i32), ("dtype", c_i32), ("out_f32", c_i32),
+                ("hi_off", c_i32), ("wi_off", c_i32)]
+
+
+class RpnLevelParams(C.Structure):
+    _fields_ = [("head", c_void_p),
+                ("n_img", c_i32), ("Hi", c_i32), ("Wi", c_i32), ("A", c_i32), ("head_c", c_i32),
+                ("stride_px", c_i32),
+                ("cell_anchors", (c_float * 4) * 3),
+                ("level", c_i32), ("kmax", c_i32), ("slot_off", c_i32), ("slots_per_img", c_i32),
+                ("clip_x", c_float), ("clip_y", c_float),
+                ("cand_boxes", c_void_p), ("cand_scores", c_void_p), ("cand_level", c_void_p), ("cand_valid", c_void_p),
+                ("workspace", c_void_p)]
+
+
+class NmsParams(C.Structure):
+    _fields_ = [("boxes", c_void_p), ("scores", c_void_p), ("group", c_void_p), ("valid", c_void_p),
+                ("n_img", c_i32), ("n_slots", c_i32), ("iou_thr", c_float), ("max_out", c_i32), ("trick_max_numel", c_i32),
+                ("out_boxes", c_void_p), ("out_scores", c_void_p), ("out_index", c_void_p), ("out_count", c_void_p),
+                ("workspace", c_void_p)]
+
+
+class RoiAlignParams(C.Structure):
+    _fields_ = [("feat", c_void_p * 4), ("Hl", c_i32 * 4), ("Wl", c_i32 * 4), ("scale", c_float * 4),
+                ("n_levels", c_i32), ("min_level", c_i32), ("C", c_i32), ("P", c_i32), ("sampling", c_i32),
+                ("boxes", c_void_p), ("counts", c_void_p), ("n_img", c_i32), ("max_rois", c_i32),
+                ("out", c_void_p), ("dtype", c_i32), ("compact", c_i32), ("roi_offsets", c_void_p)]
+
+
+class BoxDecodeParams(C.Structure):
+    _fields_ = [("logits", c_void_p), ("ld", c_i32), ("prop_boxes", c_void_p), ("prop_counts", c_void_p),
+                ("n_img", c_i32), ("max_rois", c_i32),
+                ("wx", c_float), ("wy", c_float), ("ww", c_float), ("wh", c_float), ("score_thresh", c_float),
+                ("cand_boxes", c_void_p), ("cand_scores", c_void_p), ("cand_group", c_void_p), ("cand_valid", c_void_p)]
+
+
+class PostprocessParams(C.Structure):
+    _fields_ = [("boxes", c_void_p), ("counts", c_void_p), ("n_img", c_i32), ("max_dets", c_i32),
+                ("scale_xy", c_void_p), ("out_hw", c_void_p), ("out_boxes", c_void_p), ("keep", c_void_p)]
+
+
+class IuvParams(C.Structure):
+    _fields_ = [("in_", c_void_p), ("R", c_i32), ("Hs", c_i32), ("Ws", c_i32), ("in_c", c_i32),
+                ("n_coarse", c_i32), ("n_fine", c_i32),
+                ("coarse", c_void_p), ("fine", c_void_p), ("u", c_void_p), ("v", c_void_p)]
+
+
+class GroupNormParams(C.Structure):
+    _fields_ = [("x", c_void_p), ("R", c_i32), ("HW", c_i32), ("C", c_i32), ("c_stride", c_i32), ("c_off", c_i32),
+                ("groups", c_i32), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("relu", c_i32), ("dtype", c_i32)]
+
+
+class ResizeParams(C.Structure):
+    _fields_ = [("src", c_void_p), ("tmp", c_void_p), ("dst", c_void_p),
+                ("H", c_i32), ("W", c_i32), ("oh", c_i32), ("ow", c_i32), ("src_hwc", c_i32),
+                ("xtab", c_void_p), ("ytab", c_void_p), ("xprec", c_i32), ("yprec", c_i32)]
+
+
+class IuvExtractParams(C.Structure):
+    _fields_ = [("coarse", c_void_p), ("fine", c_void_p), ("u", c_void_p), ("v", c_void_p),
+                ("R", c_i32), ("S", c_i32), ("n_coarse", c_i32), ("n_fine", c_i32),
+                ("box_xywh", c_void_p), ("out_offset", c_void_p), ("labels", c_void_p), ("uv", c_void_p), ("max_hw", c_i32)]
+
+
+# every symbol include/densepose_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "dp_abi_version": (c_int, []),
+    "dp_last_error": (C.c_char_p, []),
+    "dp_preprocess_u8": (c_int, [C.POINTER(PreprocessParams), c_void_p]),
+    "dp_conv2d_nhwc": (c_int, [C.POINTER(ConvParams), c_void_p]),
+    "dp_maxpool3x3s2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dp_subsample2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dp_upsample_bilinear2x_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dp_add_nhwc": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "dp_rpn_topk_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
+    "dp_rpn_topk_decode": (c_int, [C.POINTER(RpnLevelParams), c_void_p]),
+    "dp_nms_workspace_bytes": (c_i64, [c_int, c_int]),
+    "dp_batched_nms": (c_int, [C.POINTER(NmsParams), c_void_p]),
+    "dp_roi_align_nhwc": (c_int, [C.POINTER(RoiAlignParams), c_void_p]),
+    "dp_box_decode_score": (c_int, [C.POINTER(BoxDecodeParams), c_void_p]),
+    "dp_postprocess_boxes": (c_int, [C.POINTER(PostprocessParams), c_void_p]),
+    "dp_iuv_upsample_split": (c_int, [C.POINTER(IuvParams), c_void_p]),
+    "dp_groupnorm_relu_nhwc": (c_int, [C.POINTER(GroupNormParams), c_void_p]),
+    "dp_global_avgpool_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dp_broadcast_hw_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dp_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_i64, c_void_p]),
+    "dp_resize_u8_bilinear": (c_int, [C.POINTER(ResizeParams), c_void_p]),
+    "dp_iuv_extract": (c_int, [C.POINTER(IuvExtractParams), c_void_p]),
+}
+
+
+class DensePoseHipError(RuntimeError):
+    pass
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 -shared (cross-compiles without a GPU). Built IN-TREE so it travels."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "densepose_hip.h"))
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    subprocess.check_call(["make", "-C", CSRC, "-B"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DensePoseHipError(
+            "HIP kernel library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback in the product path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dp_abi_version() != 1:
+        raise DensePoseHipError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().dp_last_error()
+        raise DensePoseHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))

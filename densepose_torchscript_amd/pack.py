@@ -1,0 +1,231 @@
+"""Weight pipeline: canonical state dict -> device-resident packed layers for the HIP kernels.
+
+* FrozenBN folded into the conv (scale into the weights, shift into the bias):
+  y = (x - mean) * rsqrt(var + 1e-5) * gamma + beta   (/root/reference/detectron2/layers/batch_norm.py:31,54-62)
+* OIHW -> [Cout_pad128][K] with K = (tap, channel) contiguous ("KRSC"), zero padded to the 128-byte K step,
+  plus the per-16-byte-chunk tap table (ktab) consumed by dp_conv2d_nhwc.
+* fc1's K axis is permuted from the reference's NCHW flatten (c, y, x) (box_head.py:70-71) to NHWC (y, x, c).
+* ConvTranspose2d(k4, s2, p1) (chart.py:45-59) is split into its four 2x2 sub-pixel convolutions.
+"""
+import numpy as np
+import torch
+
+from .lib import DP_BF16, DP_F32
+from .weights import decoder_layout, resnet_blocks
+
+BN_EPS = 1e-5
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class PackedConv:
+    """One dp_conv2d_nhwc layer resident on the device."""
+
+    def __init__(self, name, wmat, taps, bias, cin_alloc, cout, stride, hi_off, wi_off, dtype, device):
+        # wmat: float32 [Cout, ntaps, Cin] ; taps: list of (dy, dx)
+        self.name = name
+        self.dtype = dtype
+        es = 2 if dtype == DP_BF16 else 4
+        ch = 16 // es
+        co, nt, ci = wmat.shape
+        assert nt == len(taps) and ci <= cin_alloc and cin_alloc % 8 == 0
+        self.cin = cin_alloc
+        self.cout = round_up(cout, 8)
+        self.cout_w = round_up(cout, 128)
+        k = nt * cin_alloc
+        self.kpad = round_up(k, 128 // es)
+        full = np.zeros((self.cout_w, nt, cin_alloc), dtype=np.float32)
+        full[:co, :, :ci] = wmat
+        flat = np.zeros((self.cout_w, self.kpad), dtype=np.float32)
+        flat[:, :k] = full.reshape(self.cout_w, k)
+        t = torch.from_numpy(flat)
+        if dtype == DP_BF16:
+            t = t.to(torch.bfloat16)
+        self.weight = t.to(device).contiguous()
+        nchunk = self.kpad // ch
+        ktab = np.zeros((nchunk, 4), dtype=np.int32)
+        for kc in range(nchunk):
+            k0 = kc * ch
+            tap = k0 // cin_alloc
+            if tap < nt:
+                ktab[kc] = (taps[tap][0], taps[tap][1], k0 % cin_alloc, 1)
+        self.ktab = torch.from_numpy(ktab).to(device)
+        b = np.zeros((self.cout_w,), dtype=np.float32)
+        if bias is not None:
+            b[:co] = bias
+        self.bias = torch.from_numpy(b).to(device)
+        self.stride = stride
+        self.hi_off = hi_off
+        self.wi_off = wi_off
+        self.macs_per_pixel = co * nt * ci  # algorithmic MACs per output pixel (un-padded)
+
+    def nbytes(self):
+        return self.weight.numel() * self.weight.element_size() + self.ktab.numel() * 4 + self.bias.numel() * 4
+
+
+def _fold_bn(w, st, norm_name):
+    g = st[norm_name + ".weight"].astype(np.float32)
+    b = st[norm_name + ".bias"].astype(np.float32)
+    m = st[norm_name + ".running_mean"].astype(np.float32)
+    v = st[norm_name + ".running_var"].astype(np.float32)
+    scale = g * (np.float32(1.0) / np.sqrt(v + np.float32(BN_EPS)))
+    shift = b - m * scale
+    return w * scale[:, None, None, None], shift
+
+
+def conv_from_oihw(name, w, bias, cin_alloc, stride, pad, dil, dtype, device, in_hw=None):
+    co, ci, R, S = w.shape
+    taps, cols = [], []
+    for r in range(R):
+        for s in range(S):
+            dy, dx = r * dil, s * dil
+            if in_hw is not None and stride == 1:
+                # a tap that can never land inside the map for ANY output pixel contributes exactly 0
+                # (deeplab.py:33 dilation 56 on a 28x28 ROI map: only the centre tap survives)
+                H, W = in_hw
+                if (dy - pad >= H) or (dy - pad <= -H) or (dx - pad >= W) or (dx - pad <= -W):
+                    continue
+            taps.append((dy, dx))
+            cols.append(w[:, :, r, s])
+    wmat = np.stack(cols, axis=1).astype(np.float32)  # [co, ntaps, ci]
+    return PackedConv(name, wmat, taps, bias, cin_alloc, co, stride, -pad, -pad, dtype, device)
+
+
+def linear_as_conv(name, w, bias, cin_alloc, dtype, device):
+    co, ci = w.shape
+    return PackedConv(name, w.reshape(co, 1, ci).astype(np.float32), [(0, 0)], bias, cin_alloc, co, 1, 0, 0, dtype, device)
+
+
+def deconv_parity_convs(name, w_list, b_list, cin_alloc, dtype, device):
+    """w_list: ConvTranspose2d weights [Cin, Cout_i, 4, 4] concatenated along Cout. Returns {(a, b): PackedConv}.
+    out[2i+a, 2j+b] = sum over input rows iy with ky = (2i+a) + 1 - 2*iy in [0,3]:
+       a=0: (dy=0, ky=1), (dy=-1, ky=3) ;  a=1: (dy=+1, ky=0), (dy=0, ky=2)   (same for columns)."""
+    w = np.concatenate(w_list, axis=1).astype(np.float32)  # [Cin, Ctot, 4, 4]
+    bias = np.concatenate(b_list).astype(np.float32)
+    sel = {0: [(0, 1), (-1, 3)], 1: [(1, 0), (0, 2)]}
+    out = {}
+    for a in (0, 1):
+        for b in (0, 1):
+            taps, cols = [], []
+            for dy, ky in sel[a]:
+                for dx, kx in sel[b]:
+                    taps.append((dy, dx))
+                    cols.append(w[:, :, ky, kx].T)  # [Ctot, Cin]
+            wmat = np.stack(cols, axis=1)
+            out[(a, b)] = PackedConv("%s[%d%d]" % (name, a, b), wmat, taps, bias, cin_alloc, w.shape[1], 1, 0, 0, dtype, device)
+    return out
+
+
+class PackedModel:
+    def __init__(self, cfg, state, dtype, device):
+        self.cfg = cfg
+        self.dtype = dtype
+        self.device = device
+        L = {}
+        st = state
+        bu = "backbone.bottom_up."
+
+        def bnconv(name, cin_alloc, stride, pad):
+            w, shift = _fold_bn(st[name + ".weight"].astype(np.float32), st, name + ".norm")
+            return conv_from_oihw(name, w, shift, cin_alloc, stride, pad, 1, dtype, device)
+
+        def bconv(name, cin_alloc, stride=1, pad=0, dil=1, in_hw=None, bias=True):
+            return conv_from_oihw(name, st[name + ".weight"].astype(np.float32),
+                                  st[name + ".bias"].astype(np.float32) if bias else None, cin_alloc, stride, pad, dil, dtype, device, in_hw)
+
+        A8 = lambda c: round_up(c, 8)  # noqa: E731
+        L["stem"] = bnconv(bu + "stem.conv1", 8, 2, 3)
+        for stage, b, cin, cmid, cout, stride, sc in resnet_blocks(cfg):
+            p = "%s%s.%d." % (bu, stage, b)
+            if sc:
+                L[p + "shortcut"] = bnconv(p + "shortcut", A8(cin), stride, 0)
+            L[p + "conv1"] = bnconv(p + "conv1", A8(cin), stride, 0)
+            L[p + "conv2"] = bnconv(p + "conv2", A8(cmid), 1, 1)
+            L[p + "conv3"] = bnconv(p + "conv3", A8(cmid), 1, 0)
+        c = cfg.res2_out
+        F = A8(cfg.fpn_out)
+        for lvl in (2, 3, 4, 5):
+            L["fpn_lateral%d" % lvl] = bconv("backbone.fpn_lateral%d" % lvl, A8(c), 1, 0)
+            L["fpn_output%d" % lvl] = bconv("backbone.fpn_output%d" % lvl, F, 1, 1)
+            c *= 2
+        pg = "proposal_generator.rpn_head."
+        L["rpn_conv"] = bconv(pg + "conv", F, 1, 1)
+        A = len(cfg.anchor_ratios)
+        wo = st[pg + "objectness_logits.weight"].astype(np.float32)
+        wd = st[pg + "anchor_deltas.weight"].astype(np.float32)
+        w = np.concatenate([wo, wd], axis=0)  # channel a | A + 4a + c   (rpn.py:331: a*4 + coord)
+        bcat = np.concatenate([st[pg + "objectness_logits.bias"], st[pg + "anchor_deltas.bias"]]).astype(np.float32)
+        L["rpn_head"] = conv_from_oihw("rpn_head", w, bcat, F, 1, 0, 1, dtype, device)
+        self.rpn_head_c = L["rpn_head"].cout
+        # box head: fc1 K permuted (c, y, x) -> (y, x, c) over the ALLOCATED channel count
+        P = cfg.box_pool
+        w1 = st["roi_heads.box_head.fc1.weight"].astype(np.float32)
+        o = w1.shape[0]
+        w1 = w1.reshape(o, cfg.fpn_out, P, P).transpose(0, 2, 3, 1)  # [o, y, x, c]
+        w1p = np.zeros((o, P, P, F), dtype=np.float32)
+        w1p[..., : cfg.fpn_out] = w1
+        L["fc1"] = linear_as_conv("fc1", w1p.reshape(o, P * P * F), st["roi_heads.box_head.fc1.bias"], P * P * F, dtype, device)
+        fin = o
+        for i in range(1, cfg.box_num_fc):
+            n = "roi_heads.box_head.fc%d" % (i + 1)
+            L["fc%d" % (i + 1)] = linear_as_conv(n, st[n + ".weight"].astype(np.float32), st[n + ".bias"], A8(fin), dtype, device)
+            fin = st[n + ".weight"].shape[0]
+        wcls = st["roi_heads.box_predictor.cls_score.weight"].astype(np.float32)
+        wbox = st["roi_heads.box_predictor.bbox_pred.weight"].astype(np.float32)
+        L["box_out"] = linear_as_conv("box_out", np.concatenate([wcls, wbox], axis=0),
+                                      np.concatenate([st["roi_heads.box_predictor.cls_score.bias"],
+                                                      st["roi_heads.box_predictor.bbox_pred.bias"]]).astype(np.float32),
+                                      A8(fin), dtype, device)
+        if cfg.dp_decoder_on:
+            D = A8(cfg.dp_decoder_dims)
+            for lvl, n in decoder_layout(cfg):
+                for k in range(n):
+                    nm = "roi_heads.decoder.%s.%d" % (lvl, 2 * k)
+                    L[nm] = bconv(nm, F if k == 0 else D, 1, 1)
+            L["decoder_predictor"] = bconv("roi_heads.decoder.predictor", D, 1, 0)
+        hd = "roi_heads.densepose_head."
+        Pd = cfg.dp_pool
+        cin = F
+        if cfg.is_deeplab:
+            a = hd + "ASPP."
+            L["aspp0"] = bconv(a + "convs.0.0", F, 1, 0, bias=False)
+            for i, d in ((1, 6), (2, 12), (3, 56)):
+                L["aspp%d" % i] = bconv(a + "convs.%d.0" % i, F, 1, d, d, in_hw=(Pd, Pd), bias=False)
+            L["aspp4"] = bconv(a + "convs.4.1", F, 1, 0, bias=False)
+            L["aspp_project"] = bconv(a + "project.0", 5 * F, 1, 0, bias=False)
+            self.gn = {}
+            for i, nm in ((0, "convs.0.1"), (1, "convs.1.1"), (2, "convs.2.1"), (3, "convs.3.1"), (4, "convs.4.2")):
+                self.gn["aspp%d" % i] = (torch.from_numpy(st[a + nm + ".weight"].astype(np.float32)).to(device),
+                                         torch.from_numpy(st[a + nm + ".bias"].astype(np.float32)).to(device))
+        for i in range(cfg.dp_num_convs):
+            n = hd + "body_conv_fcn%d" % (i + 1)
+            L["dp_fcn%d" % (i + 1)] = bconv(n, cin, 1, 1, bias=not cfg.is_deeplab)
+            if cfg.is_deeplab:
+                self.gn["dp_fcn%d" % (i + 1)] = (torch.from_numpy(st[n + ".norm.weight"].astype(np.float32)).to(device),
+                                                 torch.from_numpy(st[n + ".norm.bias"].astype(np.float32)).to(device))
+            cin = A8(cfg.dp_head_dim)
+        pr = "roi_heads.densepose_predictor."
+        names = ("ann_index_lowres", "index_uv_lowres", "u_lowres", "v_lowres")
+        self.deconv = deconv_parity_convs("dp_predictor", [st[pr + n + ".weight"] for n in names],
+                                          [st[pr + n + ".bias"] for n in names], cin, dtype, device)
+        self.iuv_c = self.deconv[(0, 0)].cout
+        self.layers = L
+
+    def nbytes(self):
+        n = sum(l.nbytes() for l in self.layers.values()) + sum(l.nbytes() for l in self.deconv.values())
+        return n
+
+    def parameter_tensors(self):
+        """Every device tensor of the packed model, in a fixed order (RCCL broadcast of the weights)."""
+        out = []
+        for k in sorted(self.layers):
+            l = self.layers[k]
+            out += [l.weight, l.ktab, l.bias]
+        for k in sorted(self.deconv):
+            l = self.deconv[k]
+            out += [l.weight, l.ktab, l.bias]
+        for k in sorted(getattr(self, "gn", {})):
+            out += list(self.gn[k])
+        return out

@@ -1,0 +1,83 @@
+"""Drop-in counterpart of the reference's predictor callable.
+
+    predictor(original_image: uint8 Tensor[H,W,3] | [3,H,W], bgr: bool = True) -> Dict[str, Tensor]
+
+mirrors ``DefaultPredictor.forward`` (/root/reference/detectron2/engine/defaults.py:65-97) and returns the dict
+of ``detector_postprocess`` (/root/reference/detectron2/modeling/postprocessing.py:52-61): same 8 keys, dtypes,
+shapes and value semantics; tensors live on the GPU like the reference's CUDA mode (``run.py:22-29``).
+Construction mirrors ``export.py:22-34``: a config name / yaml (+ override list) and a ``.pkl`` checkpoint.
+
+Extras the reference does not have: ``predict_batch`` (N frames -> N dicts, equal to N single calls),
+frame sharding over ranks (parallel.py) and a GPU-side resize (bit-exact restatement of the CPU uint8 kernel).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .config import ModelConfig, get_config
+from .engine import Engine
+from .resize import resize_u8_device
+from .weights import check_state, load_checkpoint
+
+
+class DensePosePredictor:
+    def __init__(self, cfg, weights, dtype="bf16", device="cuda:0", resize="host"):
+        """cfg: ModelConfig | variant name | yaml path. weights: path to .pkl/.pth or a canonical state dict."""
+        if not isinstance(cfg, ModelConfig):
+            cfg = get_config(cfg)
+        self.cfg = cfg
+        state = load_checkpoint(weights) if isinstance(weights, str) else weights
+        check_state(cfg, state)
+        assert cfg.input_format in ("RGB", "BGR"), cfg.input_format
+        self.input_format = cfg.input_format
+        self.min_size = cfg.min_size
+        self.max_size = cfg.max_size
+        self.engine = Engine(cfg, state, dtype=dtype, device=device)
+        self.device = self.engine.device
+        self.resize_mode = resize  # "host": torch CPU uint8 kernel exactly as the reference (Q4) ; "device": HIP kernel
+
+    # -- defaults.py:76-89 ---------------------------------------------------------------------------------
+    def _to_chw(self, original_image, bgr):
+        if original_image.shape[2] == 3:
+            original_image = original_image.permute(2, 0, 1)
+        else:
+            assert original_image.shape[0] == 3, (
+                "Only 3 channels expected either in HWC or CHW format, got {}".format(original_image.shape))
+        if self.input_format == "RGB" and bgr:
+            original_image = original_image.flip(0)
+        return original_image
+
+    def _scale(self, height, width):
+        return min(self.min_size / min(height, width), self.max_size / max(height, width))
+
+    def _resize(self, chw):
+        height, width = int(chw.shape[1]), int(chw.shape[2])
+        k = self._scale(height, width)
+        if self.resize_mode == "device":
+            return resize_u8_device(self.engine, chw.to(self.device), k)
+        image = F.interpolate(chw.cpu()[None], scale_factor=k, mode="bilinear", align_corners=False)[0]
+        return image.to(self.device, non_blocking=True)
+
+    @torch.no_grad()
+    def __call__(self, original_image, bgr=True):
+        return self.predict_batch([original_image], bgr)[0]
+
+    forward = __call__
+
+    @torch.no_grad()
+    def predict_batch(self, images, bgr=True):
+        """N frames -> N dicts. Frames whose resized size is equal are run as one batch through the kernels."""
+        chws = [self._to_chw(im if torch.is_tensor(im) else torch.from_numpy(np.asarray(im)), bgr) for im in images]
+        resized = [self._resize(c) for c in chws]
+        groups = {}
+        for i, r in enumerate(resized):
+            groups.setdefault((int(r.shape[1]), int(r.shape[2])), []).append(i)
+        out = [None] * len(images)
+        for (h, w), idxs in groups.items():
+            batch = torch.stack([resized[i] for i in idxs])
+            orig = [(int(chws[i].shape[1]), int(chws[i].shape[2])) for i in idxs]
+            res = self.engine.forward_batch(batch, orig)
+            res = self.engine.apply_keep_filter(res)
+            for i, r in zip(idxs, res):
+                out[i] = r
+        return out

@@ -1,0 +1,245 @@
+/*
+ * densepose_hip.h - C ABI of the MI355X (gfx950) DensePose inference kernels.
+ *
+ * The reference (dajes/DensePose-TorchScript) has no FFI of its own: every arithmetic step of
+ * DefaultPredictor.forward is a torch ATen / torchvision op call. This header declares one entry
+ * point per such call site; each comment cites the reference line(s) it
+ * replaces (paths relative to the reference root). INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: raw device pointers + sizes, no torch types; every function enqueues work on the
+ *     given hipStream_t and returns immediately: 0 = ok, <0 = dp_status error (nothing launched).
+ *   - functions never allocate; workspaces are caller-provided.
+ *   - activations are NHWC ("pixels x channels"), channel count padded to a multiple of 8;
+ *     dtype is DP_F32 (parity mode, exact fp32 MFMA) or DP_BF16 (throughput mode, fp32 accumulate).
+ *   - boxes, scores, anchors, decode, IoU, softmax are always fp32.
+ */
+#ifndef DENSEPOSE_HIP_H
+#define DENSEPOSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dp_stream_t; /* hipStream_t */
+
+enum dp_dtype { DP_F32 = 0, DP_BF16 = 1 };
+
+enum dp_status {
+  DP_OK = 0,
+  DP_ERR_BAD_ARG = -1,      /* null pointer / inconsistent shape */
+  DP_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels were built for */
+  DP_ERR_LAUNCH = -3        /* hipGetLastError() after launch */
+};
+
+#define DP_ABI_VERSION 1
+int dp_abi_version(void);
+/* human-readable reason of the last non-zero return on this thread */
+const char* dp_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2  rcnn.py:162,180  (x - pixel_mean) / pixel_std ; F.pad(right/bottom, 0) ; + NCHW->NHWC, C 3->8
+ *     src: uint8 [3,h,w] planar (the output of the uint8 resize, defaults.py:89); dst: [Hp,Wp,8]
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const uint8_t* src; /* [n_img][3][h][w] */
+  void* dst;          /* [n_img][Hp][Wp][8] dtype */
+  int32_t n_img, h, w, Hp, Wp;
+  int32_t dtype;
+  float mean[3], inv_std_unused[3], std[3];
+} dp_preprocess_params;
+int dp_preprocess_u8(const dp_preprocess_params* p, dp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3-K7, K12, K14, K16-K18  wrappers.py:105-111 F.conv2d (+FrozenBN batch_norm.py:54-62 folded,
+ * + F.relu / residual add resnet.py:203-204 / FPN top-down add fpn.py:152-155), nn.Linear
+ * box_head.py:71-73 (H=W=1), ConvTranspose2d chart.py:45-59 (4 sub-pixel 2x2 convolutions).
+ *
+ * Implicit GEMM: out[m][co] = sum_k A[m][k] * Wt[co][k], m = (n,ho,wo), k = (tap, c).
+ * The K axis is described by `ktab`: one int4 {dy, dx, c0, valid} per 16-byte chunk of K, so any
+ * tap set (3x3, dilated, 7x7 stem, 2x2 sub-pixel) uses the same kernel.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* in;        /* [N][H][W][Cin] dtype, Cin % 8 == 0 */
+  const void* weight;    /* [Cout_w][Kpad] dtype, K-contiguous; Cout_w % 128 == 0, zero padded */
+  const int32_t* ktab;   /* [Kpad / chunk][4] */
+  const float* bias;     /* [Cout_w] fp32 (BN shift or conv bias), zero padded */
+  const void* residual;  /* optional, dtype; element (n,ho,wo,c) at n*rsN + (ho>>rshift)*rsH + (wo>>rshift)*rsW + c */
+  void* out;             /* element (n,ho,wo,c) at n*osN + ho*osH + wo*osW + c */
+  int32_t N, H, W, Cin;
+  int32_t Ho, Wo, Cout;  /* Cout = channels stored (multiple of 8, <= Cout_w) */
+  int32_t Cout_w, Kpad;
+  int32_t stride, pad_unused;
+  int64_t osN, osH, osW;
+  int64_t rsN, rsH, rsW;
+  int32_t rshift;
+  int32_t relu;
+  int32_t dtype;         /* dtype of in / weight / residual */
+  int32_t out_f32;       /* 1: out is fp32 regardless of dtype */
+  int32_t hi_off, wi_off; /* input pixel of output (ho,wo), tap (dy,dx): (ho*stride + hi_off + dy, wo*stride + wi_off + dx) */
+} dp_conv_params;
+int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
+
+/* K3  resnet.py:353  F.max_pool2d(k=3, s=2, p=1), NHWC */
+int dp_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, dp_stream_t stream);
+
+/* K6  fpn.py:199  F.max_pool2d(k=1, s=2) == x[:, ::2, ::2, :] */
+int dp_subsample2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, dp_stream_t stream);
+
+/* K14 roi_head.py:63,71-79  out = (accumulate ? out : 0) + bilinear_x2(in), align_corners=False */
+int dp_upsample_bilinear2x_nhwc(const void* in, void* out, int N, int H, int W, int C, int accumulate, int dtype,
+                                dp_stream_t stream);
+/* elementwise out += in (decoder level sum when no upsample is involved) */
+int dp_add_nhwc(const void* in, void* out, int64_t count, int dtype, dp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K9   proposal_utils.py:76   logits_i.topk(min(HiWiA, k)) per image and level (sorted, desc)
+ * K8   rpn.py:375-394 + box_regression.py:74-112 + anchor_generator.py:165-179  decode of the survivors
+ *      proposal_utils.py:102-116  isfinite filter, clip_boxes (Q1: x to size[1], y to size[0]), nonempty >= 0
+ * head: [n_img][Hi][Wi][16] fp32: channel a = objectness of anchor a (a<3), 3 + 4a + c = delta c.
+ * Output per image: L*kmax candidate slots: boxes [.,4], scores, level id, valid flag.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* head;      /* level map */
+  int32_t n_img, Hi, Wi, A, head_c; /* A anchors per cell (3), head_c channel stride (16) */
+  int32_t stride_px;      /* 4..64 */
+  float cell_anchors[3][4];
+  int32_t level, kmax, slot_off, slots_per_img; /* candidates of this level go to slots [slot_off, slot_off + min(n,kmax)) */
+  float clip_x, clip_y;   /* Q1: clip_x = H_pad, clip_y = W_pad */
+  float* cand_boxes;      /* [n_img][slots_per_img][4] */
+  float* cand_scores;     /* [n_img][slots_per_img] */
+  int32_t* cand_level;    /* [n_img][slots_per_img] */
+  int32_t* cand_valid;    /* [n_img][slots_per_img] */
+  void* workspace;        /* dp_rpn_topk_workspace_bytes */
+} dp_rpn_level_params;
+int64_t dp_rpn_topk_workspace_bytes(int n_img, int Hi, int Wi, int A);
+int dp_rpn_topk_decode(const dp_rpn_level_params* p, dp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K10/K13  nms.py:20 -> torchvision batched_nms + keep[:post_topk]  (proposal_utils.py:118-126,
+ *          fast_rcnn.py:129-132). Greedy, IoU > thr strict, fp32, stable score order, groups never
+ *          suppress each other; reproduces torchvision's "coordinate trick" rounding when
+ *          4*n_valid <= trick_max_numel (4000 on the reference's CPU path).
+ * in : per image n_slots candidates (boxes, scores, group, valid) in any order
+ * out: kept boxes/scores in descending score order, at most max_out, + count; also source slot idx.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* boxes; const float* scores; const int32_t* group; const int32_t* valid;
+  int32_t n_img, n_slots;
+  float iou_thr;
+  int32_t max_out;
+  int32_t trick_max_numel;
+  float* out_boxes;     /* [n_img][max_out][4] */
+  float* out_scores;    /* [n_img][max_out] */
+  int32_t* out_index;   /* [n_img][max_out] slot index of each kept box */
+  int32_t* out_count;   /* [n_img] */
+  void* workspace;      /* dp_nms_workspace_bytes */
+} dp_nms_params;
+int64_t dp_nms_workspace_bytes(int n_img, int n_slots);
+int dp_batched_nms(const dp_nms_params* p, dp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K11/K15  poolers.py:187-227 ROIPooler (level = clamp(floor(4 + log2(sqrt(area)/224 + 1e-8)))) +
+ *          roi_align.py:58 torchvision roi_align(aligned=False, sampling_ratio=2), NHWC.
+ * boxes [n_img][max_rois][4] with counts[n_img]; output row r = img*max_rois + j -> [P][P][C].
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* feat[4];     /* level maps [n_img][Hl][Wl][C] dtype; n_levels = 1 or 4 */
+  int32_t Hl[4], Wl[4];
+  float scale[4];
+  int32_t n_levels, min_level; /* min_level = 2 for p2..p5; single map: n_levels=1 */
+  int32_t C, P, sampling;
+  const float* boxes; const int32_t* counts;
+  int32_t n_img, max_rois;
+  void* out;               /* [n_img*max_rois][P][P][C] dtype (rows >= count untouched) */
+  int32_t dtype;
+  int32_t compact;         /* 1: output rows are compacted (row = prefix(counts)[img] + j) using roi_offsets */
+  const int32_t* roi_offsets; /* [n_img] exclusive prefix of counts (compact mode) */
+} dp_roi_align_params;
+int dp_roi_align_nhwc(const dp_roi_align_params* p, dp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K13  fast_rcnn.py:257-326,105-127  apply_deltas(weights 10,10,5,5) + softmax + finite filter +
+ *      score > thresh (Q2: no clip). Produces NMS candidates per image.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* logits;   /* [n_img*max_rois][ld] : col 0 = person, col 1 = background, cols 2..5 = deltas */
+  int32_t ld;
+  const float* prop_boxes; const int32_t* prop_counts; /* [n_img][max_rois][4], [n_img] */
+  int32_t n_img, max_rois;
+  float wx, wy, ww, wh, score_thresh;
+  float* cand_boxes; float* cand_scores; int32_t* cand_group; int32_t* cand_valid; /* [n_img][max_rois] */
+} dp_box_decode_params;
+int dp_box_decode_score(const dp_box_decode_params* p, dp_stream_t stream);
+
+/* K19 postprocessing.py:43-54  scale_boxes, nonempty, clip to (H,W) of the original frame */
+typedef struct {
+  const float* boxes; const int32_t* counts; int32_t n_img, max_dets;
+  const float* scale_xy;    /* [n_img][2] */
+  const float* out_hw;      /* [n_img][2] original (H, W) as float */
+  float* out_boxes; int32_t* keep; /* [n_img][max_dets][4], [n_img][max_dets] */
+} dp_postprocess_params;
+int dp_postprocess_boxes(const dp_postprocess_params* p, dp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K18  chart.py:72-74,86-89  F.interpolate(bilinear x2) of the 4 deconv outputs + split + NHWC->NCHW
+ * in : [R][Hs][Ws][Cin_stride] fp32 (channels: coarse | fine | u | v), out: 4 NCHW fp32 tensors
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* in; int32_t R, Hs, Ws, in_c;
+  int32_t n_coarse, n_fine;   /* 2|15, 25 */
+  float* coarse; float* fine; float* u; float* v;  /* [R][C][2Hs][2Ws] */
+} dp_iuv_params;
+int dp_iuv_upsample_split(const dp_iuv_params* p, dp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K17  deeplab.py:45,90,101,119 nn.GroupNorm(32, C) (+ReLU), deeplab.py:97 AdaptiveAvgPool2d(1),
+ *      deeplab.py:109 bilinear 1x1 -> HxW (== broadcast)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  void* x;               /* in/out [R][HW][c_stride] dtype, channels [c_off, c_off + C) */
+  int32_t R, HW, C, c_stride, c_off, groups;
+  const float* gamma; const float* beta; float eps; int32_t relu; int32_t dtype;
+} dp_groupnorm_params;
+int dp_groupnorm_relu_nhwc(const dp_groupnorm_params* p, dp_stream_t stream);
+int dp_global_avgpool_nhwc(const void* in, void* out, int R, int HW, int C, int dtype, dp_stream_t stream);
+int dp_broadcast_hw_nhwc(const void* in, void* out, int R, int HW, int C, int out_c_stride, int out_c_off, int dtype,
+                         dp_stream_t stream);
+
+/* dtype conversion helper (weights upload, debugging) */
+int dp_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t count, dp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * "next" rows
+ * f1  defaults.py:89  F.interpolate(uint8, scale_factor=k, bilinear) - bit-exact fixed-point resize
+ * f2  visualizer.py:10-30  per-detection resample to the box + coarse-mask * fine-argmax + UV gather
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const uint8_t* src; /* [H][W][3] interleaved (src_hwc=1) or [3][H][W] planar (src_hwc=0) */
+  uint8_t* tmp;       /* [3][H][ow] horizontal-pass result (uint8, like ATen's two-pass kernel) */
+  uint8_t* dst;       /* [3][oh][ow] planar */
+  int32_t H, W, oh, ow, src_hwc;
+  const int32_t* xtab; /* [ow][4] = {i0, i1, W0, W1} fixed-point weights of the horizontal pass */
+  const int32_t* ytab; /* [oh][4] vertical pass */
+  int32_t xprec, yprec; /* weight precision bits of each pass */
+} dp_resize_params;
+int dp_resize_u8_bilinear(const dp_resize_params* p, dp_stream_t stream);
+
+typedef struct {
+  const float* coarse; const float* fine; const float* u; const float* v; /* [R][C][S][S] */
+  int32_t R, S, n_coarse, n_fine;
+  const int32_t* box_xywh;   /* [R][4] int (truncated), w,h >= 1 */
+  const int64_t* out_offset; /* [R] element offset of detection r in labels / (2 planes) uv */
+  uint8_t* labels;           /* sum(h*w) */
+  float* uv;                 /* 2 * sum(h*w): per detection [2][h][w] */
+  int32_t max_hw;            /* max h*w over detections (grid sizing) */
+} dp_iuv_extract_params;
+int dp_iuv_extract(const dp_iuv_extract_params* p, dp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DENSEPOSE_HIP_H */

@@ -1,0 +1,79 @@
+"""The C-ABI library builds for gfx950, loads on a CPU-only host and exports every symbol include/densepose_hip.h declares.
+(No compute calls here: those need a GPU and live in the -m gpu tests.)"""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from densepose_torchscript_amd import lib
+    lib.build_library()
+    return lib
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "densepose_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(built):
+    declared = _declared_symbols()
+    assert declared == sorted(built.SYMBOLS), (declared, sorted(built.SYMBOLS))
+
+
+def test_library_exports_every_declared_symbol(built):
+    raw = ctypes.CDLL(built.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(raw, name), name
+    lib = built.load()
+    assert lib.dp_abi_version() == 1
+
+
+def test_argument_validation_without_gpu(built):
+    """Bad arguments are rejected on the host before anything is launched (error code + message)."""
+    lib = built.load()
+    p = built.ConvParams()
+    p.N, p.H, p.W, p.Ho, p.Wo, p.Cin, p.Cout = 1, 4, 4, 4, 4, 7, 8
+    rc = lib.dp_conv2d_nhwc(ctypes.byref(p), None)
+    assert rc == -1 and b"null pointer" in lib.dp_last_error()
+    q = built.NmsParams()
+    assert lib.dp_batched_nms(ctypes.byref(q), None) == -1
+    assert lib.dp_nms_workspace_bytes(2, 1000) > 2 * 1000 * 16 * 8
+    assert lib.dp_rpn_topk_workspace_bytes(8, 200, 336, 3) == 8 * 200 * 336 * 3 * 4
+
+
+def test_struct_layout_matches_c(built, tmp_path):
+    """sizeof() of every parameter struct as seen by a C compiler == ctypes.sizeof of its mirror."""
+    import subprocess
+    names = {"dp_preprocess_params": built.PreprocessParams, "dp_conv_params": built.ConvParams,
+             "dp_rpn_level_params": built.RpnLevelParams, "dp_nms_params": built.NmsParams,
+             "dp_roi_align_params": built.RoiAlignParams, "dp_box_decode_params": built.BoxDecodeParams,
+             "dp_postprocess_params": built.PostprocessParams, "dp_iuv_params": built.IuvParams,
+             "dp_groupnorm_params": built.GroupNormParams, "dp_resize_params": built.ResizeParams,
+             "dp_iuv_extract_params": built.IuvExtractParams}
+    src = '#include <stdio.h>\n#include "densepose_hip.h"\nint main(){' + "".join(
+        'printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + "return 0;}"
+    c = tmp_path / "s.c"
+    c.write_text(src)
+    exe = tmp_path / "s"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    sizes = dict(zip(out[0::2], map(int, out[1::2])))
+    for n, cls in names.items():
+        assert sizes[n] == ctypes.sizeof(cls), (n, sizes[n], ctypes.sizeof(cls))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "densepose_torchscript_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                s = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M), f
+                assert "/root/reference" not in re.sub(r'""".*?"""', "", s, flags=re.S).replace("# ", ""), f

@@ -1,0 +1,399 @@
+"""Kernel-level parity tests: each C-ABI entry point against a plain torch fp32 / oracle computation (GPU box only)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from densepose_torchscript_amd import TINY_OPTS, get_config, make_synthetic_state
+    from densepose_torchscript_amd.engine import Engine
+    cfg = get_config("densepose_rcnn_R_50_FPN_s1x", TINY_OPTS)
+    return {dt: Engine(cfg, make_synthetic_state(cfg, 0), dtype=dt) for dt in ("fp32", "bf16")}
+
+
+def _nhwc(x, calloc, tdt, dev):
+    n, c, h, w = x.shape
+    t = torch.zeros((n, h, w, calloc), dtype=torch.float32)
+    t[..., :c] = x.permute(0, 2, 3, 1)
+    return t.to(tdt).to(dev)
+
+
+def _round_bf16(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, k, stride, pad, dil, relu, residual
+    (1, 64, 20, 24, 64, 1, 1, 0, 1, True, False),
+    (2, 64, 17, 19, 256, 1, 1, 0, 1, True, True),
+    (1, 256, 20, 26, 128, 1, 2, 0, 1, False, False),
+    (1, 64, 23, 31, 64, 3, 1, 1, 1, True, False),
+    (2, 256, 13, 21, 256, 3, 1, 1, 1, False, False),
+    (1, 3, 64, 96, 64, 7, 2, 3, 1, True, False),
+    (1, 32, 28, 28, 32, 3, 1, 6, 6, False, False),
+    (1, 256, 14, 14, 15, 1, 1, 0, 1, False, False),
+    (3, 8, 9, 11, 16, 3, 1, 1, 1, True, False),
+    (1, 512, 28, 28, 512, 3, 1, 1, 1, True, False),
+]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_matches_torch(eng, dt, case):
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw, round_up
+    e = eng[dt]
+    N, Cin, H, W, Cout, k, s, p, d, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) * (1.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn((Cout,), generator=g)
+    if dt == "bf16":
+        x, w = _round_bf16(x), _round_bf16(w)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p, dilation=d)
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g)
+        if dt == "bf16":
+            res = _round_bf16(res)
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    cin_a = round_up(Cin, 8)
+    layer = conv_from_oihw("t", w.numpy(), b.numpy(), cin_a, s, p, d, e.dt, e.device)
+    xa = Act(_nhwc(x, cin_a, e.tdt, e.device), N, H, W, cin_a)
+    ra = None
+    if use_res:
+        ra = Act(_nhwc(res, layer.cout, e.tdt, e.device), N, ref.shape[2], ref.shape[3], layer.cout)
+    out = e.conv(layer, xa, relu=relu, residual=ra, out_f32=True)
+    torch.cuda.synchronize()
+    got = out.t.cpu()[..., :Cout].permute(0, 3, 1, 2).double()
+    assert got.shape == ref.shape
+    # fp32 MFMA is an exact fp32 FMA chain; bf16 inputs are exact in both -> only accumulation-order error remains
+    tol = 2e-5 if dt == "fp32" else 2e-5
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-6
+    assert err <= tol * max(scale, 1.0) * (Cin * k * k) ** 0.5, (case, err)
+    # padded output channels must be exact zeros (they feed the next layer's zero weights)
+    if layer.cout > Cout and not use_res:
+        pad = out.t.cpu()[..., Cout:]
+        assert float(pad.abs().max()) == 0.0
+
+
+def test_conv_fpn_lateral_plus_nearest_upsample(eng):
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    e = eng["fp32"]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 64, 12, 20), generator=g)
+    top = torch.randn((2, 32, 6, 10), generator=g)
+    w = torch.randn((32, 64, 1, 1), generator=g) * 0.1
+    b = torch.randn((32,), generator=g)
+    ref = F.conv2d(x, w, b) + F.interpolate(top, scale_factor=2.0, mode="nearest")
+    layer = conv_from_oihw("lat", w.numpy(), b.numpy(), 64, 1, 0, 1, e.dt, e.device)
+    out = e.conv(layer, Act(_nhwc(x, 64, e.tdt, e.device), 2, 12, 20, 64),
+                 residual=Act(_nhwc(top, 32, e.tdt, e.device), 2, 6, 10, 32), rshift=1)
+    got = out.t.cpu().permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, atol=1e-5, rtol=1e-5)
+
+
+def test_linear_and_deconv_forms(eng):
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import deconv_parity_convs, linear_as_conv
+    e = eng["fp32"]
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((300, 392), generator=g)
+    w = torch.randn((64, 392), generator=g) * 0.05
+    b = torch.randn((64,), generator=g)
+    layer = linear_as_conv("fc", w.numpy(), b.numpy(), 392, e.dt, e.device)
+    out = e.conv(layer, Act(x.to(e.device).view(300, 1, 1, 392), 300, 1, 1, 392), relu=True)
+    assert torch.allclose(out.t.cpu().view(300, 64), F.relu(F.linear(x, w, b)), atol=1e-5, rtol=1e-5)
+    # ConvTranspose2d(k4, s2, p1) as four 2x2 sub-pixel convolutions
+    xi = torch.randn((3, 32, 7, 7), generator=g)
+    w1 = torch.randn((32, 2, 4, 4), generator=g) * 0.1
+    w2 = torch.randn((32, 25, 4, 4), generator=g) * 0.1
+    b1, b2 = torch.randn((2,), generator=g), torch.randn((25,), generator=g)
+    ref = torch.cat([F.conv_transpose2d(xi, w1, b1, stride=2, padding=1), F.conv_transpose2d(xi, w2, b2, stride=2, padding=1)], dim=1)
+    convs = deconv_parity_convs("d", [w1.numpy(), w2.numpy()], [b1.numpy(), b2.numpy()], 32, e.dt, e.device)
+    Ci = convs[(0, 0)].cout
+    low = torch.zeros((3, 14, 14, Ci), dtype=torch.float32, device=e.device)
+    xa = Act(_nhwc(xi, 32, e.tdt, e.device), 3, 7, 7, 32)
+    for (a, bb), l in convs.items():
+        e.conv(l, xa, out_f32=True, out=low, out_c_stride=Ci, out_geom=(14 * 14 * Ci, 2 * 14 * Ci, 2 * Ci, (a * 14 + bb) * Ci))
+    got = low.cpu()[..., :27].permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_pool_subsample_upsample(eng, dt):
+    e = eng[dt]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 16, 13, 18), generator=g)
+    if dt == "bf16":
+        x = _round_bf16(x)
+    xa = _nhwc(x, 16, e.tdt, e.device)
+    s = e._stream()
+    out = torch.empty((2, 7, 9, 16), dtype=e.tdt, device=e.device)
+    assert e.lib.dp_maxpool3x3s2_nhwc(xa.data_ptr(), out.data_ptr(), 2, 13, 18, 16, e.dt, s) == 0
+    assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), F.max_pool2d(x, 3, 2, 1))
+    out = torch.empty((2, 7, 9, 16), dtype=e.tdt, device=e.device)
+    assert e.lib.dp_subsample2_nhwc(xa.data_ptr(), out.data_ptr(), 2, 13, 18, 16, e.dt, s) == 0
+    assert torch.equal(out.float().cpu().permute(0, 3, 1, 2), F.max_pool2d(x, 1, 2, 0))
+    up = torch.empty((2, 26, 36, 16), dtype=e.tdt, device=e.device)
+    assert e.lib.dp_upsample_bilinear2x_nhwc(xa.data_ptr(), up.data_ptr(), 2, 13, 18, 16, 0, e.dt, s) == 0
+    ref = F.interpolate(x, scale_factor=2.0, mode="bilinear", align_corners=False)
+    tol = 1e-6 if dt == "fp32" else 2e-2
+    assert torch.allclose(up.float().cpu().permute(0, 3, 1, 2), ref, atol=tol)
+    assert e.lib.dp_upsample_bilinear2x_nhwc(xa.data_ptr(), up.data_ptr(), 2, 13, 18, 16, 1, e.dt, s) == 0
+    assert torch.allclose(up.float().cpu().permute(0, 3, 1, 2), 2 * ref, atol=2 * tol)
+
+
+def _random_boxes(rng, n, size=400.0, zero_frac=0.05):
+    xy = rng.uniform(0, size, (n, 2)).astype(np.float32)
+    wh = rng.uniform(2, size / 3, (n, 2)).astype(np.float32)
+    b = np.concatenate([xy, xy + wh], 1)
+    z = rng.random(n) < zero_frac
+    b[z, 2] = b[z, 0]
+    return b
+
+
+@pytest.mark.parametrize("n_slots,groups", [(1000, 1), (900, 5), (5000, 5), (37, 2)])
+def test_batched_nms_matches_oracle(eng, n_slots, groups):
+    from oracle import ops_ref
+    e = eng["fp32"]
+    rng = np.random.default_rng(n_slots)
+    n_img = 2
+    boxes = np.stack([_random_boxes(rng, n_slots) for _ in range(n_img)])
+    scores = np.stack([rng.permutation(n_slots).astype(np.float32) / n_slots for _ in range(n_img)])
+    group = rng.integers(0, groups, (n_img, n_slots)).astype(np.int32)
+    valid = (rng.random((n_img, n_slots)) > 0.1).astype(np.int32)
+    dev = e.device
+    ob, os_, oi, oc = e.nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), torch.from_numpy(group).to(dev),
+                            torch.from_numpy(valid).to(dev), n_img, n_slots, 0.7, 300)
+    torch.cuda.synchronize()
+    for i in range(n_img):
+        v = valid[i].astype(bool)
+        idx = np.nonzero(v)[0]
+        keep = ops_ref.batched_nms(torch.from_numpy(boxes[i][v]), torch.from_numpy(scores[i][v]), torch.from_numpy(group[i][v]).long(), 0.7)
+        keep = idx[keep.numpy()][:300]
+        cnt = int(oc[i])
+        assert cnt == len(keep)
+        assert np.array_equal(oi[i, :cnt].cpu().numpy(), keep)
+        assert np.array_equal(ob[i, :cnt].cpu().numpy(), boxes[i][keep])
+        assert np.array_equal(os_[i, :cnt].cpu().numpy(), scores[i][keep])
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("multi", [True, False])
+def test_roi_align_matches_oracle(eng, dt, multi):
+    from densepose_torchscript_amd.engine import Act
+    from oracle import ops_ref
+    from oracle.ref_cpu import OracleModel
+    e = eng[dt]
+    rng = np.random.default_rng(7)
+    g = torch.Generator().manual_seed(7)
+    n_img, Cc = 2, 32
+    shapes = [(40, 56), (20, 28), (10, 14), (5, 7)] if multi else [(40, 56)]
+    maps = [torch.randn((n_img, Cc, h, w), generator=g) for h, w in shapes]
+    if dt == "bf16":
+        maps = [_round_bf16(m) for m in maps]
+    scales = [1.0 / 4, 1.0 / 8, 1.0 / 16, 1.0 / 32][: len(shapes)]
+    max_rois, P = 50, 7
+    boxes = np.stack([_random_boxes(rng, max_rois, 220.0, 0.1) for _ in range(n_img)])
+    boxes[0, 0] = [-30, -20, 500, 400]  # far outside + huge
+    boxes[0, 1] = [10, 10, 10, 10]      # zero area
+    counts = np.array([50, 33], dtype=np.int32)
+    acts = [Act(_nhwc(m, Cc, e.tdt, e.device), n_img, m.shape[2], m.shape[3], Cc) for m in maps]
+    out = torch.zeros((n_img * max_rois, P, P, Cc), dtype=e.tdt, device=e.device)
+    e.roi_align(acts, scales, torch.from_numpy(boxes).to(e.device), torch.from_numpy(counts).to(e.device), n_img, max_rois, P, 2, out)
+    torch.cuda.synchronize()
+    got = out.float().cpu().view(n_img, max_rois, P, P, Cc).permute(0, 1, 4, 2, 3)
+    for i in range(n_img):
+        b = torch.from_numpy(boxes[i, : counts[i]])
+        rois = torch.cat([torch.zeros((len(b), 1)), b], 1)
+        if multi:
+            lv = OracleModel.assign_levels(b, 2, 5)
+            ref = torch.zeros((len(b), Cc, P, P))
+            for l in range(4):
+                idx = torch.nonzero(lv == l)[:, 0]
+                ref[idx] = ops_ref.roi_align(maps[l][i:i + 1], rois[idx], P, scales[l], 2, False)
+        else:
+            ref = ops_ref.roi_align(maps[0][i:i + 1], rois, P, scales[0], 2, False)
+        tol = 2e-6 if dt == "fp32" else 3e-2
+        assert torch.allclose(got[i, : counts[i]], ref, atol=tol), (got[i, : counts[i]] - ref).abs().max()
+
+
+def test_rpn_topk_decode_matches_oracle(eng):
+    from densepose_torchscript_amd import lib as L
+    from oracle.ref_cpu import OracleModel
+    e = eng["fp32"]
+    g = torch.Generator().manual_seed(9)
+    n_img, Hi, Wi, A = 2, 48, 80, 3   # 11520 anchors > kmax -> radix select path
+    head = torch.randn((n_img, Hi, Wi, 16), generator=g)
+    head[..., 3:15] *= 0.3
+    head[0, 0, 0, 5] = float("nan")     # a NaN delta -> that anchor must be dropped if selected
+    head[0, 0, 0, 0] = 50.0             # ... and it IS selected
+    head[1, 3, 4, 1] = 40.0
+    head[1, 3, 4, 9] = 20.0             # dw above the clamp
+    head[1, :, :5, 2] = 1.2345          # exact ties among many anchors
+    kmax, stride = 200, 8
+    cell = [[-22.6, -11.3, 22.6, 11.3], [-16.0, -16.0, 16.0, 16.0], [-11.3, -22.6, 11.3, 22.6]]
+    dev = e.device
+    slots = 2 * kmax
+    cb = torch.zeros((n_img, slots, 4), device=dev)
+    cs = torch.zeros((n_img, slots), device=dev)
+    cl = torch.zeros((n_img, slots), dtype=torch.int32, device=dev)
+    cv = torch.zeros((n_img, slots), dtype=torch.int32, device=dev)
+    ws = torch.empty((e.lib.dp_rpn_topk_workspace_bytes(n_img, Hi, Wi, A),), dtype=torch.uint8, device=dev)
+    hd = head.to(dev)
+    p = L.RpnLevelParams()
+    p.head, p.n_img, p.Hi, p.Wi, p.A, p.head_c, p.stride_px = hd.data_ptr(), n_img, Hi, Wi, A, 16, stride
+    for a in range(3):
+        for c in range(4):
+            p.cell_anchors[a][c] = cell[a][c]
+    p.level, p.kmax, p.slot_off, p.slots_per_img = 1, kmax, kmax, slots
+    p.clip_x, p.clip_y = 300.0, 500.0
+    p.cand_boxes, p.cand_scores, p.cand_level, p.cand_valid = cb.data_ptr(), cs.data_ptr(), cl.data_ptr(), cv.data_ptr()
+    p.workspace = ws.data_ptr()
+    L.check(e.lib.dp_rpn_topk_decode(C.byref(p), e._stream()))
+    torch.cuda.synchronize()
+    ca = torch.tensor(cell)
+    sx = torch.arange(0, Wi * stride, stride, dtype=torch.float32)
+    sy = torch.arange(0, Hi * stride, stride, dtype=torch.float32)
+    yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+    shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), 1)
+    anchors = (shifts.view(-1, 1, 4) + ca.view(1, -1, 4)).reshape(-1, 4)
+    for i in range(n_img):
+        logits = head[i, :, :, :3].reshape(-1)
+        deltas = head[i, :, :, 3:15].reshape(-1, 4)
+        sc, idx = logits.topk(kmax)
+        got_s = cs[i, kmax:].cpu()
+        assert torch.equal(got_s, sc)   # same multiset & order of scores (ties have equal values)
+        # compare boxes through the index our kernel effectively chose: recompute with OUR order for tie groups
+        props = OracleModel.apply_deltas(deltas, anchors, (1.0, 1.0, 1.0, 1.0))
+        ours_boxes = cb[i, kmax:].cpu()
+        ours_valid = cv[i, kmax:].cpu().bool()
+        # for non-tied scores the index is unique -> direct comparison
+        uniq = torch.tensor([(logits == s).sum().item() == 1 for s in sc])
+        ref_b = props[idx]
+        fin = torch.isfinite(ref_b).all(1)
+        ref_c = OracleModel.clip_boxes(ref_b, (500.0, 300.0))  # (h=clip_y, w=clip_x) as clip_boxes reads it
+        ref_valid = fin & OracleModel.nonempty(ref_c)
+        assert torch.equal(ours_valid[uniq], ref_valid[uniq])
+        m = uniq & ref_valid
+        assert torch.allclose(ours_boxes[m], ref_c[m], atol=1e-3, rtol=1e-5)
+        assert int(cl[i, kmax:].min()) == 1 and int(cl[i, kmax:].max()) == 1
+    # tie handling: lowest indices first among equal logits
+    tie_sel = (cs[1, kmax:].cpu() == 1.2345).sum().item()
+    assert tie_sel > 0
+
+
+def test_box_decode_and_groupnorm_gap(eng):
+    from densepose_torchscript_amd import lib as L
+    from oracle.ref_cpu import OracleModel
+    e = eng["fp32"]
+    dev = e.device
+    g = torch.Generator().manual_seed(11)
+    n_img, R = 2, 40
+    logits = torch.randn((n_img * R, 8), generator=g)
+    props = torch.from_numpy(np.stack([_random_boxes(np.random.default_rng(i), R) for i in range(n_img)]))
+    counts = torch.tensor([40, 25], dtype=torch.int32)
+    cb = torch.zeros((n_img, R, 4), device=dev)
+    cs = torch.zeros((n_img, R), device=dev)
+    cg = torch.zeros((n_img, R), dtype=torch.int32, device=dev)
+    cv = torch.zeros((n_img, R), dtype=torch.int32, device=dev)
+    p = L.BoxDecodeParams()
+    ld, pd, cd = logits.to(dev), props.to(dev), counts.to(dev)
+    p.logits, p.ld, p.prop_boxes, p.prop_counts, p.n_img, p.max_rois = ld.data_ptr(), 8, pd.data_ptr(), cd.data_ptr(), n_img, R
+    p.wx, p.wy, p.ww, p.wh, p.score_thresh = 10.0, 10.0, 5.0, 5.0, 0.3
+    p.cand_boxes, p.cand_scores, p.cand_group, p.cand_valid = cb.data_ptr(), cs.data_ptr(), cg.data_ptr(), cv.data_ptr()
+    L.check(e.lib.dp_box_decode_score(C.byref(p), e._stream()))
+    torch.cuda.synchronize()
+    ref_b = OracleModel.apply_deltas(logits[:, 2:6], props.view(-1, 4), (10.0, 10.0, 5.0, 5.0)).view(n_img, R, 4)
+    ref_p = F.softmax(logits[:, :2], dim=-1)[:, 0].view(n_img, R)
+    for i in range(n_img):
+        c = int(counts[i])
+        assert torch.allclose(cb[i, :c].cpu(), ref_b[i, :c], atol=1e-3, rtol=1e-5)
+        assert torch.allclose(cs[i, :c].cpu(), ref_p[i, :c], atol=1e-6)
+        near = (ref_p[i, :c] - 0.3).abs() < 1e-5
+        assert torch.equal(cv[i, :c].cpu().bool()[~near], (ref_p[i, :c] > 0.3)[~near])
+        assert int(cv[i, c:].sum()) == 0
+    # GroupNorm(32) + ReLU on a channel slice, GAP, broadcast
+    Rr, HW, Cc = 3, 49, 64
+    x = torch.randn((Rr, Cc, 7, 7), generator=g) * 2 + 0.5
+    gamma, beta = torch.randn((Cc,), generator=g), torch.randn((Cc,), generator=g)
+    buf = torch.zeros((Rr, HW, 2 * Cc), device=dev)
+    buf[..., Cc:] = x.permute(0, 2, 3, 1).reshape(Rr, HW, Cc).to(dev)
+    q = L.GroupNormParams()
+    gd, bd = gamma.to(dev), beta.to(dev)
+    q.x, q.R, q.HW, q.C, q.c_stride, q.c_off, q.groups = buf.data_ptr(), Rr, HW, Cc, 2 * Cc, Cc, 32
+    q.gamma, q.beta, q.eps, q.relu, q.dtype = gd.data_ptr(), bd.data_ptr(), 1e-5, 1, L.DP_F32
+    L.check(e.lib.dp_groupnorm_relu_nhwc(C.byref(q), e._stream()))
+    ref = F.relu(F.group_norm(x, 32, gamma, beta, 1e-5)).permute(0, 2, 3, 1).reshape(Rr, HW, Cc)
+    assert torch.allclose(buf[..., Cc:].cpu(), ref, atol=2e-5)
+    assert float(buf[..., :Cc].abs().max()) == 0.0
+    xin = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    pooled = torch.empty((Rr, Cc), device=dev)
+    assert e.lib.dp_global_avgpool_nhwc(xin.data_ptr(), pooled.data_ptr(), Rr, HW, Cc, L.DP_F32, e._stream()) == 0
+    assert torch.allclose(pooled.cpu(), x.mean(dim=(2, 3)), atol=1e-5)
+    bc = torch.zeros((Rr, HW, 2 * Cc), device=dev)
+    assert e.lib.dp_broadcast_hw_nhwc(pooled.data_ptr(), bc.data_ptr(), Rr, HW, Cc, 2 * Cc, Cc, L.DP_F32, e._stream()) == 0
+    assert torch.equal(bc[..., Cc:].cpu(), pooled.cpu()[:, None, :].expand(Rr, HW, Cc))
+
+
+def test_resize_and_iuv_extract(eng):
+    from densepose_torchscript_amd import lib as L
+    from densepose_torchscript_amd.resize import resize_u8_device
+    from oracle.ref_cpu import extract_iuv
+    e = eng["fp32"]
+    dev = e.device
+    rng = np.random.default_rng(13)
+    for (H, W, mn, mx) in [(480, 640, 800, 1333), (1080, 1920, 800, 1333), (96, 160, 128, 213), (333, 517, 800, 1333)]:
+        img = torch.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8))
+        k = min(mn / min(H, W), mx / max(H, W))
+        ref = F.interpolate(img.permute(2, 0, 1)[None], scale_factor=k, mode="bilinear", align_corners=False)[0]
+        got = resize_u8_device(e, img.to(dev), k, src_hwc=True)
+        assert torch.equal(got.cpu(), ref), (H, W)
+        got = resize_u8_device(e, img.permute(2, 0, 1).contiguous().to(dev), k, src_hwc=False)
+        assert torch.equal(got.cpu(), ref), (H, W)
+    # IUV extraction (visualizer.py:10-30)
+    g = torch.Generator().manual_seed(14)
+    R, S = 3, 28
+    out = {"pred_boxes": torch.tensor([[3.2, 4.9, 60.7, 90.1], [10.0, 10.0, 10.5, 80.0], [0.0, 0.0, 120.0, 33.3]]),
+           "pred_densepose_coarse_segm": torch.randn((R, 2, S, S), generator=g),
+           "pred_densepose_fine_segm": torch.randn((R, 25, S, S), generator=g),
+           "pred_densepose_u": torch.rand((R, 25, S, S), generator=g),
+           "pred_densepose_v": torch.rand((R, 25, S, S), generator=g)}
+    ref = extract_iuv(out)
+    xywh = out["pred_boxes"].clone()
+    xywh[:, 2:] -= xywh[:, :2]
+    xywh = xywh.long()
+    xywh[:, 2:] = xywh[:, 2:].clamp(min=1)
+    hw = (xywh[:, 2] * xywh[:, 3]).numpy()
+    offs = np.zeros((R,), dtype=np.int64)
+    offs[1:] = np.cumsum(hw)[:-1]
+    labels = torch.zeros((int(hw.sum()),), dtype=torch.uint8, device=dev)
+    uv = torch.zeros((2 * int(hw.sum()),), dtype=torch.float32, device=dev)
+    t = {k: v.to(dev) for k, v in out.items()}
+    bx, od = xywh.int().to(dev), torch.from_numpy(offs).to(dev)
+    p = L.IuvExtractParams()
+    p.coarse, p.fine, p.u, p.v = (t["pred_densepose_coarse_segm"].data_ptr(), t["pred_densepose_fine_segm"].data_ptr(),
+                                  t["pred_densepose_u"].data_ptr(), t["pred_densepose_v"].data_ptr())
+    p.R, p.S, p.n_coarse, p.n_fine = R, S, 2, 25
+    p.box_xywh, p.out_offset, p.labels, p.uv, p.max_hw = bx.data_ptr(), od.data_ptr(), labels.data_ptr(), uv.data_ptr(), int(hw.max())
+    L.check(e.lib.dp_iuv_extract(C.byref(p), e._stream()))
+    torch.cuda.synchronize()
+    for r in range(R):
+        w, h = int(xywh[r, 2]), int(xywh[r, 3])
+        lab = labels[offs[r]: offs[r] + h * w].cpu().view(h, w)
+        u_ = uv[2 * offs[r]: 2 * offs[r] + 2 * h * w].cpu().view(2, h, w)
+        mism = (lab.long() != ref[r][0]).float().mean().item()
+        assert mism <= 0.002, mism  # argmax flips only where two bilinear samples tie within 1 ulp
+        same = lab.long() == ref[r][0]
+        assert torch.allclose(u_[:, same], ref[r][1][:, same], atol=1e-5)
