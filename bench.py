@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): images/sec of the DensePose hot path on R_50_FPN_s1x, 800x1333 frames,
+batch 8 per GPU, bf16 operands / fp32 accumulate, detections pinned to R = 8 per image.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" = one pass of the whole path (device resize -> backbone -> RPN -> box head -> DensePose head -> IUV maps)
+over one batch of synthetic frames that are already resident in HBM. Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_DENSE = 2.5e15   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: "~2.5 PF dense")
+PEAK_F32_MATRIX = 157.3e12
+HBM_PEAK = 8.0e12
+
+
+def make_frames(n, start, hw, device):
+    h, w = hw
+    return [torch.from_numpy(np.random.default_rng(1234 + start + i).integers(0, 256, (h, w, 3), dtype=np.uint8)).to(device)
+            for i in range(n)]
+
+
+def cpu_baseline(cfg, state, hw, budget_s):
+    """The oracle (a CPU port of the reference path, oracle/ref_cpu.py) timed on this box's host cores on a bounded
+    sample of the same workload (same weights, same frames, same R)."""
+    from oracle.ref_cpu import OracleModel
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = OracleModel(cfg, state)
+    frames = [torch.from_numpy(np.random.default_rng(1234 + i).integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)) for i in range(4)]
+    t0 = time.time()
+    model(frames[0])  # warm-up (also bounds the sample: if one frame is already slow, time fewer)
+    warm = time.time() - t0
+    n_timed = max(1, min(3, int(budget_s / max(warm, 1e-3))))
+    times = []
+    for i in range(n_timed):
+        t0 = time.time()
+        model(frames[1 + i % 3])
+        times.append(time.time() - t0)
+    return {"value": round(len(times) / sum(times), 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d frame(s) 800x1333 R_50_FPN_s1x fp32 after 1 warm-up, oracle/ref_cpu.py (torch %s CPU + C roi_align/nms), p50 %.0f ms/img"
+                      % (len(times), torch.__version__, 1e3 * float(np.median(times)))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--config", default="densepose_rcnn_R_50_FPN_s1x")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dets", type=int, default=8, help="detections per image (R), pinned via TEST.DETECTIONS_PER_IMAGE")
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    args = ap.parse_args()
+
+    from densepose_torchscript_amd import get_config, make_synthetic_state
+    from densepose_torchscript_amd import parallel
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    from densepose_torchscript_amd.weights import param_shapes
+    import torch.distributed as dist
+
+    rank, local_rank, world = parallel.init_distributed()
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+
+    cfg = get_config(args.config, ["TEST.DETECTIONS_PER_IMAGE", args.dets])
+    # weights: generated on rank 0 only, then ONE coalesced RCCL broadcast of the packed device tensors (xGMI)
+    if rank == 0:
+        state = make_synthetic_state(cfg, 0)
+    else:
+        state = {k: np.zeros(s, dtype=np.float32) for k, s in param_shapes(cfg).items()}
+        for k in state:
+            if k.endswith("running_var"):
+                state[k] += 1.0
+    pred = DensePosePredictor(cfg, state, dtype=args.dtype, device=device, resize="device")
+    if world > 1:
+        parallel.broadcast_tensors(pred.engine.model.parameter_tensors(), src=0)
+    eng = pred.engine
+    hw = (args.height, args.width)
+    frames = make_frames(args.batch, rank * args.batch, hw, device)  # weak scaling: every rank owns `batch` frames
+    torch.cuda.synchronize()
+
+    def step():
+        return pred.predict_batch(frames)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    step_times = []
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        t0 = time.perf_counter()
+        out = step()
+        torch.cuda.synchronize()
+        step_times.append(time.perf_counter() - t0)
+    barrier()
+    elapsed = time.perf_counter() - t_begin
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    dets = [int(o["scores"].shape[0]) for o in out]
+    flops_step = eng.flops_last
+
+    # ---- roofline of the dominant kernel, HIP events on the launch stream, same K steps of the same workload ----
+    eng.prof = []
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    agg = {}
+    for cls, flops, e0, e1, name in eng.prof:
+        a = agg.setdefault(cls, [0, 0.0, 0])
+        a[0] += flops
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += 1
+    eng.prof = None
+    dom = max(agg, key=lambda c: agg[c][1])
+    dflops, dsec, dcalls = agg[dom]
+    peak = PEAK_BF16_DENSE if args.dtype == "bf16" else PEAK_F32_MATRIX
+    roofline = {"bound": "mfma", "kernel": dom, "achieved": round(dflops / dsec / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+                "frac": round(dflops / dsec / peak, 4), "traffic": None,
+                "launches_per_step": dcalls // args.steps, "avg_launch_us": round(1e6 * dsec / dcalls, 2),
+                "alg_gflop_per_launch": round(dflops / dcalls / 1e9, 3),
+                "share_of_step_time": round(dsec / args.steps / (elapsed / args.steps), 3),
+                "all_conv_classes": {c: {"tflops": round(v[0] / v[1] / 1e12, 2), "calls_per_step": v[2] // args.steps,
+                                         "ms_per_step": round(1e3 * v[1] / args.steps, 3)} for c, v in agg.items()}}
+
+    result = None
+    if rank == 0:
+        images = args.batch * world * args.steps
+        result = {
+            "metric": "images/sec at 1/2/4/8 MI355X, R_50_FPN_s1x 800x1333; p50 ms/img",
+            "value": round(images / elapsed, 3), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            "p50_ms_per_img": round(1e3 * float(np.median(step_times)) / args.batch, 3),
+            "config": {"workload": "%s batch=%d/GPU %dx%d uint8 frames resident in HBM, R=%d detections/img (measured %s), synthetic seeded weights"
+                                   % (args.config, args.batch, hw[0], hw[1], args.dets, dets),
+                       "global_batch": args.batch * world, "parallelism": "frame-sharded dp%d, no hot-loop collective" % world,
+                       "alg_gflop_per_image": round(flops_step / args.batch / 1e9, 1)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, state, hw, args.cpu_budget_s)
+            result["config"]["gpu_over_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,7 @@ class Engine:
         self.keep_intermediates = False
         self.inter = {}
         self.flops_last = 0
+        self.prof = None  # list of (kernel class, algorithmic flops, start event, end event) when profiling
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -99,8 +100,16 @@ class Engine:
         p.dtype = self.dt
         p.out_f32 = 1 if out_f32 else 0
         p.hi_off, p.wi_off = layer.hi_off, layer.wi_off
-        L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
-        self.flops_last += 2 * layer.macs_per_pixel * N * Ho * Wo
+        flops = 2 * layer.macs_per_pixel * N * Ho * Wo
+        if self.prof is not None and N * Ho * Wo > 0:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
+            e1.record()
+            self.prof.append(("conv_igemm_bn64" if layer.cout <= 64 else "conv_igemm_bn128", flops, e0, e1, layer.name))
+        else:
+            L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
+        self.flops_last += flops
         return Act(out, N, Ho, Wo, cs)
 
     # ------------------------------------------------------------------ stages

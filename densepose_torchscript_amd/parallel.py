@@ -1,0 +1,70 @@
+"""Frame-level data parallelism over the GPUs of one node: one process per GPU, the packed weights are
+broadcast once from rank 0 over RCCL/xGMI, then every rank runs the whole path on its own shard of frames - no
+collective in the hot loop. (The reference has no distributed code at all; frames are its only independent unit.)
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_distributed(backend=None):
+    rank, local_rank, world = env_rank()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [lo, hi) of n_items frames for this rank (sizes differ by at most one)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_tensors(tensors, src=0, bucket_bytes=256 << 20):
+    """Broadcast a fixed-order list of tensors from `src`, coalesced per dtype into few large messages
+    (xGMI links are per-peer: a handful of 100+ MB messages beats hundreds of small ones)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dt, group in by_dtype.items():
+        bucket, size = [], 0
+        for t in group + [None]:
+            if t is not None and size + t.numel() * t.element_size() <= bucket_bytes:
+                bucket.append(t)
+                size += t.numel() * t.element_size()
+                continue
+            if bucket:
+                flat = torch.cat([b.reshape(-1) for b in bucket])
+                dist.broadcast(flat, src=src)
+                off = 0
+                for b in bucket:
+                    b.copy_(flat[off:off + b.numel()].view_as(b))
+                    off += b.numel()
+            bucket, size = ([t], t.numel() * t.element_size()) if t is not None else ([], 0)
+
+
+def gather_results(local_results, dst=0):
+    """Optional: collect the per-frame result dicts (variable R) on rank `dst`, in frame order."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_results
+    world = dist.get_world_size()
+    cpu = [{k: v.cpu() for k, v in r.items()} for r in local_results]
+    out = [None] * world if dist.get_rank() == dst else None
+    dist.gather_object(cpu, out, dst=dst)
+    if dist.get_rank() != dst:
+        return None
+    return [r for part in out for r in part]

@@ -54,6 +54,8 @@ class DensePosePredictor:
         height, width = int(chw.shape[1]), int(chw.shape[2])
         k = self._scale(height, width)
         if self.resize_mode == "device":
+            if chw.stride(0) == 1 and chw.stride(2) == 3:  # permuted view of a contiguous HWC frame: resize straight from HWC
+                return resize_u8_device(self.engine, chw.permute(1, 2, 0).to(self.device), k, src_hwc=True)
             return resize_u8_device(self.engine, chw.to(self.device), k)
         image = F.interpolate(chw.cpu()[None], scale_factor=k, mode="bilinear", align_corners=False)[0]
         return image.to(self.device, non_blocking=True)

@@ -59,8 +59,11 @@ def resize_u8_device(engine, img, k, src_hwc=False):
     xt, px = axis_table(W, ow, k)
     yt, py = axis_table(H, oh, k)
     dev = engine.device
-    xtab = torch.from_numpy(xt).to(dev)
-    ytab = torch.from_numpy(yt).to(dev)
+    cache = engine.__dict__.setdefault("_resize_tables", {})
+    key = (H, W, oh, ow, k)
+    if key not in cache:  # tables are uploaded once per frame geometry
+        cache[key] = (torch.from_numpy(xt).to(dev), torch.from_numpy(yt).to(dev))
+    xtab, ytab = cache[key]
     tmp = torch.empty((3, H, ow), dtype=torch.uint8, device=dev)
     dst = torch.empty((3, oh, ow), dtype=torch.uint8, device=dev)
     p = L.ResizeParams()

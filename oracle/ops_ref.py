@@ -24,11 +24,54 @@ Because the oracle and the reference share these two restatements (the reference
 here with them as its torchvision stand-in), they are additionally pinned by
 hand-computed known-answer tests in tests/test_oracle_ops.py.
 """
+import ctypes
+import os
+
 import numpy as np
 import torch
 
+# Optional C build of the same two kernels (oracle/ops_c.c -> oracle/_ops_c.so, `make -C oracle`): identical
+# arithmetic and operation order, only faster; tests/test_oracle_ops.py checks C == numpy/torch bit for bit.
+_C = None
+_so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ops_c.so")
+if os.path.exists(_so) and os.environ.get("ORACLE_NO_C", "0") != "1":
+    try:
+        _C = ctypes.CDLL(_so)
+        _C.oracle_nms_f32.restype = ctypes.c_int
+    except OSError:
+        _C = None
 
-def roi_align(input, rois, output_size, spatial_scale=1.0, sampling_ratio=-1, aligned=False):
+
+def roi_align(input, rois, output_size, spatial_scale=1.0, sampling_ratio=-1, aligned=False, backend=None):
+    use_c = (_C is not None) if backend is None else (backend == "c")
+    if use_c and input.dtype == torch.float32 and rois.shape[0] > 0:
+        if isinstance(output_size, (tuple, list)):
+            assert output_size[0] == output_size[1]
+            output_size = output_size[0]
+        x = input.contiguous()
+        r = rois.to(torch.float32).contiguous()
+        N, Cc, H, W = x.shape
+        K = r.shape[0]
+        out = torch.empty((K, Cc, int(output_size), int(output_size)), dtype=torch.float32)
+        _C.oracle_roi_align_f32(ctypes.c_void_p(x.data_ptr()), N, Cc, H, W, ctypes.c_void_p(r.data_ptr()), K, int(output_size),
+                                ctypes.c_float(spatial_scale), int(sampling_ratio), int(bool(aligned)), ctypes.c_void_p(out.data_ptr()))
+        return out
+    return _roi_align_torch(input, rois, output_size, spatial_scale, sampling_ratio, aligned)
+
+
+def nms(boxes, scores, iou_threshold, backend=None):
+    use_c = (_C is not None) if backend is None else (backend == "c")
+    if use_c and boxes.shape[0] > 0:
+        b = boxes.detach().to(torch.float32).contiguous()
+        order = torch.sort(scores.detach().to(torch.float32), descending=True, stable=True)[1].contiguous()
+        keep = torch.empty((b.shape[0],), dtype=torch.int64)
+        nk = _C.oracle_nms_f32(ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(order.data_ptr()), int(b.shape[0]),
+                               ctypes.c_float(iou_threshold), ctypes.c_void_p(keep.data_ptr()))
+        return keep[:nk].clone()
+    return _nms_numpy(boxes, scores, iou_threshold)
+
+
+def _roi_align_torch(input, rois, output_size, spatial_scale=1.0, sampling_ratio=-1, aligned=False):
     """input [N,C,H,W] float, rois [K,5] (batch, x1, y1, x2, y2) -> [K,C,ph,pw]."""
     if isinstance(output_size, int):
         output_size = (output_size, output_size)
@@ -113,7 +156,7 @@ def roi_align(input, rois, output_size, spatial_scale=1.0, sampling_ratio=-1, al
     return out
 
 
-def nms(boxes, scores, iou_threshold):
+def _nms_numpy(boxes, scores, iou_threshold):
     """Greedy NMS; returns kept indices (int64) in descending score order."""
     n = boxes.shape[0]
     if n == 0:

@@ -29,6 +29,18 @@ def _run(name, dtype="fp32", keep=False, resize="host"):
     return meta, z, cfg, pred, {k: v.cpu() for k, v in out.items()}
 
 
+def _assert_rows_match(boxes, scores, ref_boxes, ref_scores, score_tol=1e-4, box_tol=2e-3):
+    """Score-sorted lists agree up to permutations inside groups of scores closer than the fp32 noise of ~50 layers
+    (the reference's own order inside such a group is decided by 1e-6 differences: SURVEY §7 hard part 1, Q8)."""
+    np.testing.assert_allclose(scores, ref_scores, atol=score_tol)
+    used = np.zeros(len(boxes), dtype=bool)
+    for i in range(len(ref_boxes)):
+        cand = np.nonzero((np.abs(scores - ref_scores[i]) <= score_tol) & ~used)[0]
+        d = np.abs(boxes[cand] - ref_boxes[i]).max(axis=1)
+        assert len(cand) and d.min() <= box_tol * max(1.0, np.abs(ref_boxes[i]).max()), (i, ref_boxes[i], ref_scores[i])
+        used[cand[d.argmin()]] = True
+
+
 TINY = ["tiny_r50_s1x_a", "tiny_r50_s1x_b", "tiny_r50_legacy", "tiny_r101_s1x", "tiny_r50_dl", "tiny_r101_dl"]
 
 
@@ -62,8 +74,8 @@ def test_fp32_matches_reference_golden(name):
         props, pscores, pcounts = inter["proposals"]
         n = int(pcounts[0])
         assert n == z["stage/proposal_boxes"].shape[0]
-        np.testing.assert_allclose(props[0, :n].cpu().numpy(), z["stage/proposal_boxes"], atol=1e-3, rtol=1e-5)
-        np.testing.assert_allclose(pscores[0, :n].cpu().numpy(), z["stage/objectness_logits"], atol=1e-4)
+        _assert_rows_match(props[0, :n].cpu().numpy(), pscores[0, :n].cpu().numpy(), z["stage/proposal_boxes"],
+                           z["stage/objectness_logits"])
         if cfg.dp_decoder_on:
             ref = z["stage/decoder_out"]
             got = _nchw(inter["decoder_out"]).numpy()[:, : ref.shape[1]]

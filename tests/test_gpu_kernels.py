@@ -241,7 +241,7 @@ def test_rpn_topk_decode_matches_oracle(eng):
     head[0, 0, 0, 0] = 50.0             # ... and it IS selected
     head[1, 3, 4, 1] = 40.0
     head[1, 3, 4, 9] = 20.0             # dw above the clamp
-    head[1, :, :5, 2] = 1.2345          # exact ties among many anchors
+    head[1, :, :5, 2] = 2.2             # 240 exact ties that straddle the top-k boundary
     kmax, stride = 200, 8
     cell = [[-22.6, -11.3, 22.6, 11.3], [-16.0, -16.0, 16.0, 16.0], [-11.3, -22.6, 11.3, 22.6]]
     dev = e.device
@@ -289,9 +289,11 @@ def test_rpn_topk_decode_matches_oracle(eng):
         m = uniq & ref_valid
         assert torch.allclose(ours_boxes[m], ref_c[m], atol=1e-3, rtol=1e-5)
         assert int(cl[i, kmax:].min()) == 1 and int(cl[i, kmax:].max()) == 1
-    # tie handling: lowest indices first among equal logits
-    tie_sel = (cs[1, kmax:].cpu() == 1.2345).sum().item()
-    assert tie_sel > 0
+    # tie handling: exactly the needed number of tied entries is taken
+    lg = head[1, :, :, :3].reshape(-1)
+    n_gt = int((lg > 2.2).sum())
+    assert n_gt < kmax < n_gt + int((lg == 2.2).sum())
+    assert int((cs[1, kmax:].cpu() == 2.2).sum()) == kmax - n_gt
 
 
 def test_box_decode_and_groupnorm_gap(eng):

@@ -85,3 +85,23 @@ def test_batched_nms_levels_do_not_interact_both_strategies():
     ref = torch.cat(ref)
     ref = ref[scores[ref].sort(descending=True)[1]]
     assert k1.tolist() == ref.tolist()
+
+
+def test_c_backend_equals_numpy_backend_bit_for_bit():
+    import pytest
+    if ops_ref._C is None:
+        pytest.skip("oracle/_ops_c.so not built")
+    rng = np.random.default_rng(3)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 16, 30, 44), generator=g)
+    xy = rng.uniform(-20, 150, (200, 2)).astype(np.float32)
+    wh = rng.uniform(0, 90, (200, 2)).astype(np.float32)
+    rois = torch.from_numpy(np.concatenate([rng.integers(0, 2, (200, 1)).astype(np.float32), xy, xy + wh], 1))
+    for P, sc in ((7, 0.25), (14, 0.125), (3, 1.0)):
+        a = ops_ref.roi_align(x, rois, P, sc, 2, False, backend="c")
+        b = ops_ref.roi_align(x, rois, P, sc, 2, False, backend="torch")
+        assert torch.equal(a, b)
+    boxes = torch.from_numpy(np.concatenate([xy, xy + wh], 1))
+    scores = torch.from_numpy(rng.random(200).astype(np.float32))
+    for thr in (0.3, 0.5, 0.7):
+        assert torch.equal(ops_ref.nms(boxes, scores, thr, backend="c"), ops_ref.nms(boxes, scores, thr, backend="numpy"))
