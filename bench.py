@@ -34,8 +34,11 @@ def cpu_baseline(cfg, state, hw, budget_s):
     """The oracle (a CPU port of the reference path, oracle/ref_cpu.py) timed on this box's host cores on a bounded
     sample of the same workload (same weights, same frames, same R)."""
     from oracle.ref_cpu import OracleModel
-    cores = os.cpu_count() or 1
+    # torch's CPU convolutions stop scaling (and then collapse) beyond ~32 threads on this class of host
+    # (measured on the 2x64-core EPYC GPU box: 3x3 conv 256->256 @200x336: 61 ms at 32 threads, 149 ms at 128, 595 ms at 256)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     model = OracleModel(cfg, state)
     frames = [torch.from_numpy(np.random.default_rng(1234 + i).integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)) for i in range(4)]
     t0 = time.time()

@@ -24,6 +24,10 @@
 
 namespace {
 
+// native clang vectors (HIP's uint4/int4 are structs; arrays of them ended up in scratch memory)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int kBM = 128;       // pixels per workgroup
 constexpr int kKB = 128;       // bytes of K per step
 constexpr int kThreads = 256;
@@ -31,7 +35,7 @@ constexpr int kThreads = 256;
 struct ConvArgs {
   const void* in;
   const void* weight;
-  const int4* ktab;
+  const i32x4* ktab;
   const float* bias;
   const void* residual;
   void* out;
@@ -42,21 +46,27 @@ struct ConvArgs {
 
 __device__ __forceinline__ int swz(int r) { return (-(r >> 2)) & 3; }
 
+// 16 zero bytes in global memory: out-of-image / K-padding chunks are loaded from here, so every staging load is
+// unconditional (a predicated load makes hipcc branch around it and wait vmcnt(0) per load: serialised round trips).
+__device__ u32x4 g_zero16 = {0u, 0u, 0u, 0u};
+
 template <typename T>
 struct Mma;
 template <>
 struct Mma<uint16_t> {
-  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
 };
 template <>
 struct Mma<float> {
-  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+    // whole-vector bit_cast, then index: bit_cast of a single ext-vector element (a.y ...) silently read element 0
+    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], c, 0, 0, 0);
   }
 };
 
@@ -125,35 +135,32 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
   const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
   const T* __restrict__ wgt = reinterpret_cast<const T*>(p.weight) + (long long)(n0 + lrow) * p.Kpad + c * CH;
 
-  uint4 ra[A_PASSES], rb[B_PASSES];
+  u32x4 ra[A_PASSES], rb[B_PASSES];
+  const T* __restrict__ zsrc = reinterpret_cast<const T*>(&g_zero16);
+  unsigned char* const st_a = smem + plane * A_PLANE + st_off;
+  unsigned char* const st_b = smem + A_BUF + plane * B_PLANE + st_off;
 
-  auto load_tile = [&](int kt) {
-    const int4 e = p.ktab[kt * 8 + c];
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      const int hi = a_hi0[i] + e.x;
-      const int wi = a_wi0[i] + e.y;
-      const bool ok = e.w && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (ok) {
-        const long long off = (long long)(a_pix[i] + hi * p.W + wi) * p.Cin + e.z;
-        v = *reinterpret_cast<const uint4*>(in + off);
-      }
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      rb[i] = *reinterpret_cast<const uint4*>(wgt + (long long)(32 * i) * p.Kpad + kt * KT);
-    }
-  };
-  auto store_tile = [&](int buf) {
-    unsigned char* a = smem + buf * BUF + plane * A_PLANE + st_off;
-    unsigned char* b = smem + buf * BUF + A_BUF + plane * B_PLANE + st_off;
-#pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) *reinterpret_cast<uint4*>(a + i * 32 * 64) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) *reinterpret_cast<uint4*>(b + i * 32 * 64) = rb[i];
-  };
+// NOTE: plain macros, not lambdas: a closure capturing ra/rb by reference made hipcc keep them in scratch memory.
+#define DP_LOAD_TILE(KT_IDX, E)                                                                        \
+  {                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                             \
+      const int hi = a_hi0[i] + (E).x;                                                                 \
+      const int wi = a_wi0[i] + (E).y;                                                                 \
+      const bool ok = (E).w && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;           \
+      const long long off = (long long)(a_pix[i] + hi * p.W + wi) * p.Cin + (E).z;                     \
+      const T* src = ok ? (in + off) : zsrc;                                                           \
+      ra[i] = *reinterpret_cast<const u32x4*>(src);                                                    \
+    }                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i)                                               \
+        rb[i] = *reinterpret_cast<const u32x4*>(wgt + (long long)(32 * i) * p.Kpad + (KT_IDX) * KT);   \
+  }
+#define DP_STORE_TILE(BUF_IDX)                                                                         \
+  {                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i)                                               \
+        *reinterpret_cast<u32x4*>(st_a + (BUF_IDX) * BUF + i * 32 * 64) = ra[i];                       \
+    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i)                                               \
+        *reinterpret_cast<u32x4*>(st_b + (BUF_IDX) * BUF + i * 32 * 64) = rb[i];                       \
+  }
 
   f32x4 acc[TC][TP];
 #pragma unroll
@@ -170,30 +177,39 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
   const int a_row0 = (wp * TP * 16) * 64;     // pixel rows of this wave
   const int b_row0 = (wc * TC * 16) * 64;     // cout rows of this wave
 
-  load_tile(0);
-  store_tile(0);
+  const int nk = p.n_ktiles;
+  // the tap-table entry is fetched one K-step ahead of the loads that depend on it
+  i32x4 e_next = p.ktab[(nk > 1 ? 8 : 0) + c];
+  {
+    const i32x4 e0 = p.ktab[c];
+    DP_LOAD_TILE(0, e0);
+  }
+  DP_STORE_TILE(0);
   __syncthreads();
 
-  const int nk = p.n_ktiles;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt + 1 < nk) {
+      DP_LOAD_TILE(kt + 1, e_next);
+      const int kn = kt + 2 < nk ? kt + 2 : nk - 1;
+      e_next = p.ktab[kn * 8 + c];
+    }
     const unsigned char* sa = smem + cur * BUF + a_row0;
     const unsigned char* sb = smem + cur * BUF + A_BUF + b_row0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int ro = ks ? rd_p1 : rd_p0;
-      uint4 fp[TP], fc[TC];
+      u32x4 fp[TP], fc[TC];
 #pragma unroll
-      for (int j = 0; j < TP; ++j) fp[j] = *reinterpret_cast<const uint4*>(sa + ks * A_PLANE + j * 16 * 64 + ro);
+      for (int j = 0; j < TP; ++j) fp[j] = *reinterpret_cast<const u32x4*>(sa + ks * A_PLANE + j * 16 * 64 + ro);
 #pragma unroll
-      for (int i = 0; i < TC; ++i) fc[i] = *reinterpret_cast<const uint4*>(sb + ks * B_PLANE + i * 16 * 64 + ro);
+      for (int i = 0; i < TC; ++i) fc[i] = *reinterpret_cast<const u32x4*>(sb + ks * B_PLANE + i * 16 * 64 + ro);
 #pragma unroll
       for (int i = 0; i < TC; ++i)
 #pragma unroll
         for (int j = 0; j < TP; ++j) Mma<T>::run(fc[i], fp[j], acc[i][j]);
     }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
+    if (kt + 1 < nk) DP_STORE_TILE(cur ^ 1);
     __syncthreads();
   }
 
@@ -229,6 +245,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
   }
 }
 
+#undef DP_LOAD_TILE
+#undef DP_STORE_TILE
+
 template <typename T, int BN>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
   constexpr int lds = 2 * (2 * kBM * 64 + 2 * BN * 64);
@@ -259,7 +278,7 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   DP_REQUIRE(p->stride >= 1, "dp_conv2d_nhwc: stride");
   DP_REQUIRE(M < (1ll << 31) && (long long)p->N * p->H * p->W * p->Cin < (1ll << 31), "dp_conv2d_nhwc: tensor too large for 32-bit pixel index");
   ConvArgs a;
-  a.in = p->in; a.weight = p->weight; a.ktab = reinterpret_cast<const int4*>(p->ktab); a.bias = p->bias;
+  a.in = p->in; a.weight = p->weight; a.ktab = reinterpret_cast<const i32x4*>(p->ktab); a.bias = p->bias;
   a.residual = p->residual; a.out = p->out;
   a.N = p->N; a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.Ho = p->Ho; a.Wo = p->Wo; a.Cout = p->Cout; a.Kpad = p->Kpad;
   a.stride = p->stride; a.hi_off = p->hi_off; a.wi_off = p->wi_off; a.relu = p->relu; a.rshift = p->rshift; a.out_f32 = p->out_f32;
