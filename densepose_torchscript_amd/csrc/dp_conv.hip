@@ -21,6 +21,7 @@
 //   * workgroup ids are remapped so that consecutive tiles (same pixel rows, neighbouring cout tiles)
 //     run on the same XCD and share its L2.
 #include "dp_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -70,18 +71,85 @@ struct Mma<float> {
   }
 };
 
-template <typename T, int BN>
-__global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs p) {
+
+// ---- LDS-staged epilogue -------------------------------------------------------------------------------------
+// The accumulators (4 consecutive channels of one pixel per lane) are parked in LDS as an fp32 [rows][COLS] tile
+// (16-byte chunks XOR-swizzled by row so that the ds_write_b128 of 8 consecutive rows hits 8 different slots), then
+// read back row-major: each lane owns 8 consecutive channels of one pixel -> bias/residual/ReLU in fp32, ONE 16-byte
+// (bf16) or two 16-byte (fp32) stores, 16 lanes covering 256 contiguous bytes of the NHWC row (full 128-B lines
+// instead of four 32-byte fragments per line: the direct epilogue was store-issue bound).
+template <int COLS>
+__device__ __forceinline__ void park_acc(float* lds, int row, int col, const f32x4& v) {
+  const int chunk = (col >> 2) ^ (row & 7);
+  *reinterpret_cast<f32x4*>(lds + row * COLS + chunk * 4) = v;
+}
+
+template <typename T, int COLS, int NTHREADS>
+__device__ __forceinline__ void drain_rows(const ConvArgs& p, const float* lds, int rows, int m_base, int n_base, int tid) {
+  constexpr int LPR = COLS / 8;              // lanes per pixel row
+  constexpr int RPP = NTHREADS / LPR;        // rows per pass
+  const int q = tid % LPR;                   // 8-channel group inside the tile
+  const int r0 = tid / LPR;
+  const int co = n_base + q * 8;
+  if (co >= p.Cout) return;
+  const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + co);
+  const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + co + 4);
+  const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+  for (int r = r0; r < rows; r += RPP) {
+    const int m = m_base + r;
+    if (m >= p.M) break;
+    const int c0 = ((2 * q) ^ (r & 7)) * 4, c1 = ((2 * q + 1) ^ (r & 7)) * 4;
+    f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + r * COLS + c0);
+    f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + r * COLS + c1);
+    v0 += b0;
+    v1 += b1;
+    const int n = m / p.HoWo;
+    const int rem = m - n * p.HoWo;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    if (res) {
+      const long long rb = n * p.rsN + (ho >> p.rshift) * p.rsH + (wo >> p.rshift) * p.rsW + co;
+      const float4 ra = load4(res + rb), rc = load4(res + rb + 4);
+      v0[0] += ra.x; v0[1] += ra.y; v0[2] += ra.z; v0[3] += ra.w;
+      v1[0] += rc.x; v1[1] += rc.y; v1[2] += rc.z; v1[3] += rc.w;
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
+    }
+    const long long ob = n * p.osN + ho * p.osH + wo * p.osW + co;
+    if (p.out_f32 || sizeof(T) == 4) {
+      float* o = reinterpret_cast<float*>(p.out) + ob;
+      *reinterpret_cast<f32x4*>(o) = v0;
+      *reinterpret_cast<f32x4*>(o + 4) = v1;
+    } else {
+      u32x4 pk;
+      pk[0] = pack_bf16x2(v0[0], v0[1]); pk[1] = pack_bf16x2(v0[2], v0[3]);
+      pk[2] = pack_bf16x2(v1[0], v1[1]); pk[3] = pack_bf16x2(v1[2], v1[3]);
+      *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.out) + ob) = pk;
+    }
+  }
+}
+
+#define DP_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define DP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// NPL = 64-byte K planes per pipeline stage: 2 (128-byte K step, 64 KiB LDS, 2 workgroups/CU) for compute-heavy layers,
+// 1 (64-byte K step, 32 KiB LDS, 4 workgroups/CU) for the short-K, HBM-bound 1x1 layers where resident workgroups
+// (bytes in flight per CU), not per-step efficiency, set the speed.
+template <typename T, int BN, int NPL>
+__global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int ES = sizeof(T);
   constexpr int CH = 16 / ES;           // elements per chunk
-  constexpr int KT = kKB / ES;          // elements of K per step
+  constexpr int KT = NPL * 64 / ES;     // elements of K per step
   constexpr int A_PLANE = kBM * 64;
   constexpr int B_PLANE = BN * 64;
-  constexpr int A_BUF = 2 * A_PLANE;
-  constexpr int B_BUF = 2 * B_PLANE;
+  constexpr int A_BUF = NPL * A_PLANE;
+  constexpr int B_BUF = NPL * B_PLANE;
   constexpr int BUF = A_BUF + B_BUF;
-  constexpr int A_PASSES = kBM / 32;
-  constexpr int B_PASSES = BN / 32;
+  // staging: one global_load_lds_dwordx4 wave-instruction fills 16 rows x 64 B of one plane (1 KiB, lane-linear)
+  constexpr int A_GROUPS = kBM / 16 / 4;  // 16-row groups per wave
+  constexpr int B_GROUPS = BN / 16 / 4;
   // wave tiling: BN=128 -> 2(pixels) x 2(couts) waves of 64x64 ; BN=64 -> 4 x 1 waves of 32 x 64
   constexpr int WAVES_C = BN / 64;
   constexpr int WAVES_P = 4 / WAVES_C;
@@ -104,20 +172,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = wave % WAVES_P;
   const int wc = wave / WAVES_P;
 
-  // ---- staging assignment: thread -> (row lrow + 32*i, chunk c) ----
-  const int lrow = tid >> 3;
-  const int c = tid & 7;
-  const int plane = c >> 2;
-  const int st_off = plane * 0 + ((lrow ^ plane) * 64) + (((c & 3) ^ swz(lrow)) << 4);  // + plane*PLANE added per region
+  // ---- staging assignment. Lane l of a wave-instruction lands at LDS byte l*16 of the 1-KiB piece, i.e. physical
+  //      (row = l>>2, slot = l&3); the slot holds logical chunk slot ^ swz(row), so the swizzle is applied to the
+  //      per-lane SOURCE address (the LDS-DMA destination is lane-linear by construction).
+  const int srow = lane >> 2;
+  const int scc = (lane & 3) ^ swz(srow);  // logical 16-byte chunk inside the plane (0..3)
 
-  int a_hi0[A_PASSES], a_wi0[A_PASSES], a_pix[A_PASSES];
+  int a_hi0[A_GROUPS], a_wi0[A_GROUPS], a_pix[A_GROUPS];
 #pragma unroll
-  for (int i = 0; i < A_PASSES; ++i) {
-    const int m = m0 + lrow + 32 * i;
+  for (int i = 0; i < A_GROUPS; ++i) {
+    const int m = m0 + (wave * A_GROUPS + i) * 16 + srow;
     if (m < p.M) {
       const int n = m / p.HoWo;
       const int rem = m - n * p.HoWo;
@@ -133,33 +201,28 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
     }
   }
   const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
-  const T* __restrict__ wgt = reinterpret_cast<const T*>(p.weight) + (long long)(n0 + lrow) * p.Kpad + c * CH;
-
-  u32x4 ra[A_PASSES], rb[B_PASSES];
+  const T* __restrict__ wgt =
+      reinterpret_cast<const T*>(p.weight) + (long long)(n0 + wave * B_GROUPS * 16 + srow) * p.Kpad + scc * CH;
   const T* __restrict__ zsrc = reinterpret_cast<const T*>(&g_zero16);
-  unsigned char* const st_a = smem + plane * A_PLANE + st_off;
-  unsigned char* const st_b = smem + A_BUF + plane * B_PLANE + st_off;
+  unsigned char* const lds_a = smem + (wave * A_GROUPS) * 1024;           // + buf*BUF + plane*A_PLANE + i*1024
+  unsigned char* const lds_b = smem + A_BUF + (wave * B_GROUPS) * 1024;   // + buf*BUF + plane*B_PLANE + i*1024
 
-// NOTE: plain macros, not lambdas: a closure capturing ra/rb by reference made hipcc keep them in scratch memory.
-#define DP_LOAD_TILE(KT_IDX, E)                                                                        \
-  {                                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                             \
-      const int hi = a_hi0[i] + (E).x;                                                                 \
-      const int wi = a_wi0[i] + (E).y;                                                                 \
-      const bool ok = (E).w && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;           \
-      const long long off = (long long)(a_pix[i] + hi * p.W + wi) * p.Cin + (E).z;                     \
-      const T* src = ok ? (in + off) : zsrc;                                                           \
-      ra[i] = *reinterpret_cast<const u32x4*>(src);                                                    \
-    }                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i)                                               \
-        rb[i] = *reinterpret_cast<const u32x4*>(wgt + (long long)(32 * i) * p.Kpad + (KT_IDX) * KT);   \
-  }
-#define DP_STORE_TILE(BUF_IDX)                                                                         \
-  {                                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i)                                               \
-        *reinterpret_cast<u32x4*>(st_a + (BUF_IDX) * BUF + i * 32 * 64) = ra[i];                       \
-    _Pragma("unroll") for (int i = 0; i < B_PASSES; ++i)                                               \
-        *reinterpret_cast<u32x4*>(st_b + (BUF_IDX) * BUF + i * 32 * 64) = rb[i];                       \
+// out-of-image / K-padding chunks are fetched from a 16-byte zero page: every LDS-DMA is unconditional
+#define DP_STAGE_TILE(KT_IDX, EN, BUF_IDX)                                                                        \
+  {                                                                                                               \
+    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                                          \
+      _Pragma("unroll") for (int i = 0; i < A_GROUPS; ++i) {                                                      \
+        const int hi = a_hi0[i] + (EN)[pl][0], wi = a_wi0[i] + (EN)[pl][1];                                       \
+        const bool ok = (EN)[pl][3] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;              \
+        const long long off = (long long)(a_pix[i] + hi * p.W + wi) * p.Cin + (EN)[pl][2];                        \
+        const T* src = ok ? (in + off) : zsrc;                                                                    \
+        __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(src), DP_LDS_PTR(lds_a + (BUF_IDX) * BUF + pl * A_PLANE + i * 1024), 16, 0, 0); \
+      }                                                                                                           \
+      _Pragma("unroll") for (int i = 0; i < B_GROUPS; ++i) {                                                      \
+        const T* wsrc = wgt + (long long)(16 * i) * p.Kpad + (KT_IDX) * KT + pl * 4 * CH;                         \
+        __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(wsrc), DP_LDS_PTR(lds_b + (BUF_IDX) * BUF + pl * B_PLANE + i * 1024), 16, 0, 0); \
+      }                                                                                                           \
+    }                                                                                                             \
   }
 
   f32x4 acc[TC][TP];
@@ -171,97 +234,301 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_kernel(const ConvArgs 
   // fragment read offsets (row = lane&15 inside a 16-row tile, chunk = lane>>4)
   const int fr = lane & 15;
   const int fq = lane >> 4;
-  const int rd_sw = (fq ^ swz(fr)) << 4;
-  const int rd_p0 = fr * 64 + rd_sw;          // plane 0
-  const int rd_p1 = (fr ^ 1) * 64 + rd_sw;    // plane 1 (row pairs swapped)
+  const int rd_off = fr * 64 + ((fq ^ swz(fr)) << 4);
   const int a_row0 = (wp * TP * 16) * 64;     // pixel rows of this wave
   const int b_row0 = (wc * TC * 16) * 64;     // cout rows of this wave
 
-  const int nk = p.n_ktiles;
-  // the tap-table entry is fetched one K-step ahead of the loads that depend on it
-  i32x4 e_next = p.ktab[(nk > 1 ? 8 : 0) + c];
+  const int nk = p.n_ktiles * (2 / NPL);      // K steps (n_ktiles counts 128-byte steps)
+  // tap-table entries of this lane's chunk(s) are fetched one K-step ahead of the loads that need them
+  i32x4 en[NPL];
   {
-    const i32x4 e0 = p.ktab[c];
-    DP_LOAD_TILE(0, e0);
+    i32x4 e0[NPL];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) e0[pl] = p.ktab[pl * 4 + scc];
+    DP_STAGE_TILE(0, e0, 0);
+    const int k1 = nk > 1 ? 1 : 0;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) en[pl] = p.ktab[(k1 * NPL + pl) * 4 + scc];
   }
-  DP_STORE_TILE(0);
-  __syncthreads();
+  __syncthreads();  // (drains the LDS-DMA: hipcc emits vmcnt(0) before the barrier)
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      DP_LOAD_TILE(kt + 1, e_next);
+      DP_STAGE_TILE(kt + 1, en, cur ^ 1);
       const int kn = kt + 2 < nk ? kt + 2 : nk - 1;
-      e_next = p.ktab[kn * 8 + c];
-    }
-    const unsigned char* sa = smem + cur * BUF + a_row0;
-    const unsigned char* sb = smem + cur * BUF + A_BUF + b_row0;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ro = ks ? rd_p1 : rd_p0;
+      for (int pl = 0; pl < NPL; ++pl) en[pl] = p.ktab[(kn * NPL + pl) * 4 + scc];
+    }
+    const unsigned char* sa = smem + cur * BUF + a_row0 + rd_off;
+    const unsigned char* sb = smem + cur * BUF + A_BUF + b_row0 + rd_off;
+#pragma unroll
+    for (int ks = 0; ks < NPL; ++ks) {
       u32x4 fp[TP], fc[TC];
 #pragma unroll
-      for (int j = 0; j < TP; ++j) fp[j] = *reinterpret_cast<const u32x4*>(sa + ks * A_PLANE + j * 16 * 64 + ro);
+      for (int j = 0; j < TP; ++j) fp[j] = *reinterpret_cast<const u32x4*>(sa + ks * A_PLANE + j * 16 * 64);
 #pragma unroll
-      for (int i = 0; i < TC; ++i) fc[i] = *reinterpret_cast<const u32x4*>(sb + ks * B_PLANE + i * 16 * 64 + ro);
+      for (int i = 0; i < TC; ++i) fc[i] = *reinterpret_cast<const u32x4*>(sb + ks * B_PLANE + i * 16 * 64);
 #pragma unroll
       for (int i = 0; i < TC; ++i)
 #pragma unroll
         for (int j = 0; j < TP; ++j) Mma<T>::run(fc[i], fp[j], acc[i][j]);
     }
-    if (kt + 1 < nk) DP_STORE_TILE(cur ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds channels co..co+3 of pixel m for each (i, j) ----
-  const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
+  // ---- epilogue (the last loop barrier guarantees every wave is done reading the operand tiles) ----
+  // two passes of 64 pixel rows: the fp32 staging tile then needs only 64 x BN x 4 bytes, so single-K-step layers
+  // (the HBM-bound 1x1s of res2) run with 32 KiB of LDS and four workgroups per CU instead of two
+  float* const stage = reinterpret_cast<float*>(smem);
+  constexpr int W_PER_HALF = WAVES_P / 2;  // pixel-waves per 64-row half
 #pragma unroll
-  for (int j = 0; j < TP; ++j) {
-    const int m = m0 + wp * TP * 16 + j * 16 + fr;
-    if (m >= p.M) continue;
-    const int n = m / p.HoWo;
-    const int rem = m - n * p.HoWo;
-    const int ho = rem / p.Wo;
-    const int wo = rem - ho * p.Wo;
-    const long long obase = n * p.osN + ho * p.osH + wo * p.osW;
-    long long rbase = 0;
-    if (res) rbase = n * p.rsN + (ho >> p.rshift) * p.rsH + (wo >> p.rshift) * p.rsW;
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();
+    if (wp / W_PER_HALF == half) {
+      const int r0 = (wp % W_PER_HALF) * TP * 16;
 #pragma unroll
-    for (int i = 0; i < TC; ++i) {
-      const int co = n0 + wc * TC * 16 + i * 16 + fq * 4;
-      if (co >= p.Cout) continue;
-      const float4 bv = *reinterpret_cast<const float4*>(p.bias + co);
-      float4 v = make_float4(acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w);
-      if (res) {
-        const float4 rv = load4(res + rbase + co);
-        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-      }
-      if (p.relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-      }
-      if (p.out_f32) store4(reinterpret_cast<float*>(p.out) + obase + co, v);
-      else store4(reinterpret_cast<T*>(p.out) + obase + co, v);
+      for (int j = 0; j < TP; ++j)
+#pragma unroll
+        for (int i = 0; i < TC; ++i) park_acc<BN>(stage, r0 + j * 16 + fr, wc * TC * 16 + i * 16 + fq * 4, acc[i][j]);
     }
+    __syncthreads();
+    drain_rows<T, BN, kThreads>(p, stage, 64, m0 + half * 64, n0, tid);
   }
 }
 
-#undef DP_LOAD_TILE
-#undef DP_STORE_TILE
+#undef DP_STAGE_TILE
 
-template <typename T, int BN>
-int launch_conv(const ConvArgs& a, hipStream_t stream) {
-  constexpr int lds = 2 * (2 * kBM * 64 + 2 * BN * 64);
+// =====================================================================================================
+// Large-tile variant for the layers that carry most of the FLOPs (3x3 / 1x1 with Cin*esize % 64 == 0, Cout % 256 == 0,
+// thousands of pixel tiles): 256 pixels x 256 couts per workgroup, 8 waves (64 couts x 128 pixels each, 128 accumulator
+// VGPRs), K consumed in 64-byte planes through a 4-slot LDS ring (4 x 32 KiB) filled by global_load_lds.
+// Three planes stay in flight behind a COUNTED s_waitcnt vmcnt(N) + raw s_barrier (a plain __syncthreads() would drain
+// them), so HBM/L2 latency is covered by ~3 x 32 MFMAs per wave; bytes per FLOP are half those of the 128 x 128 tile.
+// A 64-byte plane lies inside one tap, so the tap-table entry is wave-uniform and fetched with scalar loads (no VMEM
+// traffic besides the LDS-DMA itself, which keeps the vmcnt arithmetic exact).
+// =====================================================================================================
+constexpr int kBigThreads = 512;
+constexpr int kBigM = 256, kBigN = 256;
+constexpr int kBigPlane = 256 * 64;          // bytes of one operand plane
+constexpr int kBigSlot = 2 * kBigPlane;      // A plane + B plane
+constexpr int kBigRing = 4;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBigThreads, 2) void conv_igemm_big_kernel(const ConvArgs p) {
+  constexpr int ES = sizeof(T);
+  constexpr int CH = 16 / ES;
+  constexpr int PE = 64 / ES;  // elements of K per plane
+  constexpr int TC = 4, TP = 8;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  int tile;
+  {
+    const int nwg = p.n_tiles, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  }
+  const int mt = tile / p.tiles_n;
+  const int nt = tile - mt * p.tiles_n;
+  const int m0 = mt * kBigM;
+  const int n0 = nt * kBigN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 3;   // cout quarter (64)
+  const int wp = wave >> 2;  // pixel half (128)
+
+  const int srow = lane >> 2;
+  const int scc = (lane & 3) ^ swz(srow);
+
+  // per-lane descriptors of the two pixel rows this lane stages (rows 32*wave + 16*i + srow of the tile)
+  int a_hi0[2], a_wi0[2], a_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wave * 32 + i * 16 + srow;
+    if (m < p.M) {
+      const int n = m / p.HoWo;
+      const int rem = m - n * p.HoWo;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      a_hi0[i] = ho * p.stride + p.hi_off;
+      a_wi0[i] = wo * p.stride + p.wi_off;
+      a_off[i] = ((n * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + scc * CH;  // may be "virtual" (negative) at the border
+    } else {
+      a_hi0[i] = -(1 << 28);
+      a_wi0[i] = 0;
+      a_off[i] = 0;
+    }
+  }
+  const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
+  const T* __restrict__ wgt = reinterpret_cast<const T*>(p.weight) + (long long)(n0 + wave * 32 + srow) * p.Kpad + scc * CH;
+  const T* __restrict__ zsrc = reinterpret_cast<const T*>(&g_zero16);
+  unsigned char* const lds_st = smem + wave * 2048;  // this wave's 2 KiB of each plane
+  // constant address space: the only way to get s_load (a vector load here would sit in vmcnt and drain the ring)
+  const __attribute__((address_space(4))) i32x4* ktab_c = (const __attribute__((address_space(4))) i32x4*)p.ktab;
+
+#define DP_BIG_STAGE(S_IDX, E)                                                                                     \
+  {                                                                                                                \
+    const int tap_off = ((E)[0] * p.W + (E)[1]) * p.Cin + (E)[2];                                                  \
+    unsigned char* dst = lds_st + ((S_IDX) & (kBigRing - 1)) * kBigSlot;                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+      const bool ok = (E)[3] && (unsigned)(a_hi0[i] + (E)[0]) < (unsigned)p.H && (unsigned)(a_wi0[i] + (E)[1]) < (unsigned)p.W; \
+      const T* src = ok ? (in + (a_off[i] + tap_off)) : zsrc;                                                      \
+      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(src), DP_LDS_PTR(dst + i * 1024), 16, 0, 0);                  \
+    }                                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+      const T* wsrc = wgt + (long long)(16 * i) * p.Kpad + (S_IDX) * PE;                                           \
+      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(wsrc), DP_LDS_PTR(dst + kBigPlane + i * 1024), 16, 0, 0);     \
+    }                                                                                                              \
+  }
+
+  f32x4 acc[TC][TP];
+#pragma unroll
+  for (int i = 0; i < TC; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+  const int rd_off = fr * 64 + ((fq ^ swz(fr)) << 4);
+  const unsigned char* const rd_a = smem + (wp * TP * 16) * 64 + rd_off;
+  const unsigned char* const rd_b = smem + kBigPlane + (wc * TC * 16) * 64 + rd_off;
+
+  const int ns = p.n_ktiles * 2;  // number of 64-byte planes along K
+  {
+    const i32x4 t0 = ktab_c[0];
+    DP_BIG_STAGE(0, t0);
+    if (ns > 1) { const i32x4 t1 = ktab_c[4]; DP_BIG_STAGE(1, t1); }
+    if (ns > 2) { const i32x4 t2 = ktab_c[8]; DP_BIG_STAGE(2, t2); }
+  }
+  // tap entry (wave-uniform, scalar load) of the plane staged in the NEXT step: fetched one step ahead of its use
+  i32x4 e_nx = ktab_c[(ns > 3 ? 3 : 0) * 4];
+
+  for (int s = 0; s < ns; ++s) {
+    // plane s has landed once at most the younger planes' LDS-DMAs (4 per plane per wave) are outstanding
+    if (s + 2 < ns) wait_vmcnt<8>();
+    else if (s + 1 < ns) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    const int slot = (s & (kBigRing - 1)) * kBigSlot;
+    u32x4 fp[TP], fc[TC];
+#pragma unroll
+    for (int i = 0; i < TC; ++i) fc[i] = *reinterpret_cast<const u32x4*>(rd_b + slot + i * 16 * 64);
+#pragma unroll
+    for (int j = 0; j < TP; ++j) fp[j] = *reinterpret_cast<const u32x4*>(rd_a + slot + j * 16 * 64);
+    // refill the slot that every wave finished reading before this barrier (it held plane s-1)
+    if (s + 3 < ns) {
+      DP_BIG_STAGE(s + 3, e_nx);
+      e_nx = ktab_c[(s + 4 < ns ? s + 4 : s + 3) * 4];
+    }
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+      for (int j = 0; j < TP; ++j) Mma<T>::run(fc[i], fp[j], acc[i][j]);
+  }
+
+  // ---- epilogue: two passes (pixel halves) through the 128 KiB of LDS as an fp32 [128][256] staging tile ----
+  float* const stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();  // operands (half 0) / previous staging tile (half 1) no longer needed
+    if (wp == half) {
+#pragma unroll
+      for (int j = 0; j < TP; ++j)
+#pragma unroll
+        for (int i = 0; i < TC; ++i) park_acc<kBigN>(stage, j * 16 + fr, wc * TC * 16 + i * 16 + fq * 4, acc[i][j]);
+    }
+    __syncthreads();
+    drain_rows<T, kBigN, kBigThreads>(p, stage, 128, m0 + half * 128, n0, tid);
+  }
+}
+#undef DP_BIG_STAGE
+
+template <typename T>
+int launch_conv_big(const ConvArgs& a, hipStream_t stream) {
+  constexpr int lds = kBigRing * kBigSlot;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_big_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BN>), dim3(a.n_tiles), dim3(kThreads), lds, stream, a);
+  hipLaunchKernelGGL((conv_igemm_big_kernel<T>), dim3(a.n_tiles), dim3(kBigThreads), lds, stream, a);
+  return dp_check_launch("conv_igemm_big_kernel");
+}
+
+template <typename T, int BN, int NPL>
+int launch_conv(const ConvArgs& a, hipStream_t stream) {
+  constexpr int buf = NPL * (kBM * 64 + BN * 64);   // one operand stage
+  constexpr int staging = 64 * BN * 4;              // epilogue staging (half tile, fp32)
+  constexpr int full = 2 * buf > staging ? 2 * buf : staging;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BN, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, full);
+    attr_set = true;
+  }
+  // single-step layers never touch the second stage
+  const int steps = a.n_ktiles * (2 / NPL);
+  const int lds = steps == 1 ? (buf > staging ? buf : staging) : full;
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, NPL>), dim3(a.n_tiles), dim3(kThreads), lds, stream, a);
   return dp_check_launch("conv_igemm_kernel");
 }
 
+template <typename T, int BN>
+int launch_conv_k(const ConvArgs& a, hipStream_t stream) {
+  // K <= 512 bytes-pairs... short-K layers (<= 8 steps of 128 B): 64-byte steps, 32 KiB LDS, 4 workgroups per CU
+  return a.n_ktiles <= 8 ? launch_conv<T, BN, 1>(a, stream) : launch_conv<T, BN, 2>(a, stream);
+}
+
 }  // namespace
+
+// Kernel choice: estimated speed = plateau speed of the tile shape x wave-quantisation efficiency on this chip
+// (workgroups / (CUs x resident workgroups per CU), rounded up to whole rounds). Plateau ratios measured on MI355X
+// (profiles/): large tile ~1.17x the 128x128 tile when both fill the chip.
+enum { DP_CONV_K64 = 0, DP_CONV_K128 = 1, DP_CONV_BIG = 2 };
+
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n = prop.multiProcessorCount;
+    else
+      n = 256;
+  }
+  return n;
+}
+
+static int choose_conv_kernel(const dp_conv_params* p, long long M) {
+  const int es = p->dtype == DP_F32 ? 4 : 2;
+  if (p->Cout <= 64) return DP_CONV_K64;
+  const bool legal = (p->Cin * es) % 64 == 0 && p->Cout % kBigN == 0 && p->Cout_w % kBigN == 0;
+  const char* fe = getenv("DP_CONV_BIG");  // test/debug knob - 0: never, 1: whenever legal
+  if (fe) return (legal && atoi(fe) == 1) ? DP_CONV_BIG : DP_CONV_K128;
+  if (!legal) return DP_CONV_K128;
+  // short-K layers are HBM/latency bound: many small resident workgroups beat the deep ring (which needs K to fill)
+  if ((long long)p->Kpad * es < 1024) return DP_CONV_K128;
+  const double cus = (double)num_cus();
+  const double tb = (double)((M + kBigM - 1) / kBigM) * (p->Cout / kBigN);
+  const double ts = (double)((M + kBM - 1) / kBM) * ((p->Cout + 127) / 128);
+  const double rb = tb / cus, rs = ts / (2.0 * cus);               // rounds (1 resp. 2 workgroups resident per CU)
+  const double eff_b = rb / (double)(long long)(rb + 0.999999), eff_s = rs / (double)(long long)(rs + 0.999999);
+  return (1.17 * eff_b > eff_s) ? DP_CONV_BIG : DP_CONV_K128;
+}
+
+extern "C" int dp_conv2d_kernel_class(const dp_conv_params* p) {
+  if (!p) return -1;
+  return choose_conv_kernel(p, (long long)p->N * p->Ho * p->Wo);
+}
 
 extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   DP_REQUIRE(p != nullptr, "dp_conv2d_nhwc: null params");
@@ -284,14 +551,20 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   a.stride = p->stride; a.hi_off = p->hi_off; a.wi_off = p->wi_off; a.relu = p->relu; a.rshift = p->rshift; a.out_f32 = p->out_f32;
   a.osN = p->osN; a.osH = p->osH; a.osW = p->osW; a.rsN = p->rsN; a.rsH = p->rsH; a.rsW = p->rsW;
   a.M = (int)M; a.HoWo = p->Ho * p->Wo; a.n_ktiles = p->Kpad * es / kKB;
-  const int tiles_m = (int)((M + kBM - 1) / kBM);
   hipStream_t s = as_stream(stream);
-  if (p->Cout <= 64) {
+  const int kc = choose_conv_kernel(p, M);
+  if (kc == DP_CONV_BIG) {
+    a.tiles_n = p->Cout / kBigN;
+    a.n_tiles = (int)((M + kBigM - 1) / kBigM) * a.tiles_n;
+    return p->dtype == DP_F32 ? launch_conv_big<float>(a, s) : launch_conv_big<uint16_t>(a, s);
+  }
+  const int tiles_m = (int)((M + kBM - 1) / kBM);
+  if (kc == DP_CONV_K64) {
     a.tiles_n = (p->Cout + 63) / 64;
     a.n_tiles = tiles_m * a.tiles_n;
-    return p->dtype == DP_F32 ? launch_conv<float, 64>(a, s) : launch_conv<uint16_t, 64>(a, s);
+    return p->dtype == DP_F32 ? launch_conv_k<float, 64>(a, s) : launch_conv_k<uint16_t, 64>(a, s);
   }
   a.tiles_n = (p->Cout + 127) / 128;
   a.n_tiles = tiles_m * a.tiles_n;
-  return p->dtype == DP_F32 ? launch_conv<float, 128>(a, s) : launch_conv<uint16_t, 128>(a, s);
+  return p->dtype == DP_F32 ? launch_conv_k<float, 128>(a, s) : launch_conv_k<uint16_t, 128>(a, s);
 }

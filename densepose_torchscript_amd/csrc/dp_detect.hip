@@ -52,9 +52,105 @@ __global__ void rpn_keys_kernel(const float* __restrict__ head, uint32_t* __rest
   }
 }
 
+// ---- stage 1 (large levels only): each workgroup keeps the top min(k, chunk) keys of an 8192-anchor chunk held in LDS.
+// The global top-k (ordered by key desc, anchor index asc) is a subset of the union of the per-chunk top-k's, so the
+// single-workgroup-per-image stage 2 then scans n_chunks*k candidates instead of Hi*Wi*A keys (p2: 25k instead of 202k).
+// Survivors are written in ascending anchor-index order (ordered compaction), which keeps stage 2's tie rule exact.
+constexpr int kChunk = 8192;
+constexpr int kChunkThreads = 256;
+
+__global__ __launch_bounds__(kChunkThreads) void rpn_chunk_select_kernel(const float* __restrict__ head, int cells, int A, int head_c, int n,
+                                                                        int k, int kcap, int n_chunks, uint32_t* __restrict__ cand_keys,
+                                                                        uint32_t* __restrict__ cand_idx) {
+  __shared__ uint32_t keys[kChunk];
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int sh_prefix, sh_need, sh_taken_gt, sh_taken_eq;
+  __shared__ unsigned int wsum_gt[kChunkThreads / 64], wsum_eq[kChunkThreads / 64];
+  const int chunk = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+  const int i0 = chunk * kChunk;
+  const int len = min(kChunk, n - i0);
+  const float* hbase = head + (long long)img * cells * head_c;
+  for (int t = tid; t < len; t += kChunkThreads) {
+    const int idx = i0 + t;
+    keys[t] = f32_to_key(hbase[(long long)(idx / A) * head_c + (idx % A)]);
+  }
+  uint32_t* okeys = cand_keys + ((long long)img * n_chunks + chunk) * kcap;
+  uint32_t* oidx = cand_idx + ((long long)img * n_chunks + chunk) * kcap;
+  const int kk = min(k, len);
+  if (tid == 0) { sh_taken_gt = 0; sh_taken_eq = 0; }
+  __syncthreads();
+  uint32_t T = 0;
+  unsigned int need_eq = 0xffffffffu;  // len <= k: everything is kept (T = 0: all keys >= T, unlimited ties)
+  if (len > kk) {
+    uint32_t prefix = 0, mask = 0;
+    unsigned int need = (unsigned)kk;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      for (int t = tid; t < 256; t += kChunkThreads) hist[t] = 0;
+      __syncthreads();
+      for (int t = tid; t < len; t += kChunkThreads) {
+        const uint32_t key = keys[t];
+        if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned int acc = 0;
+        int d = 255;
+        for (; d > 0; --d) {
+          if (acc + hist[d] >= need) break;
+          acc += hist[d];
+        }
+        sh_prefix = prefix | ((uint32_t)d << shift);
+        sh_need = need - acc;
+      }
+      __syncthreads();
+      prefix = sh_prefix;
+      need = sh_need;
+      mask |= 255u << shift;
+      __syncthreads();
+    }
+    T = prefix;
+    need_eq = need;
+  }
+  // ordered compaction: position = (#kept before me); kept = key > T, or key == T while fewer than need_eq ties were taken
+  const int lane = tid & 63, w = tid >> 6;
+  for (int t0 = 0; t0 < len; t0 += kChunkThreads) {
+    const int t = t0 + tid;
+    const uint32_t key = t < len ? keys[t] : 0u;
+    const bool gt = (t < len) && (len <= kk ? true : key > T);
+    const bool eq = (t < len) && !(len <= kk) && key == T;
+    const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+    if (lane == 0) { wsum_gt[w] = (unsigned)__popcll(bg); wsum_eq[w] = (unsigned)__popcll(be); }
+    __syncthreads();
+    unsigned int gt_before = sh_taken_gt, eq_before = sh_taken_eq;
+    for (int ww = 0; ww < w; ++ww) { gt_before += wsum_gt[ww]; eq_before += wsum_eq[ww]; }
+    const unsigned long long lm = (1ull << lane) - 1ull;
+    const unsigned int my_gt = gt_before + (unsigned)__popcll(bg & lm);
+    const unsigned int my_eq = eq_before + (unsigned)__popcll(be & lm);
+    const bool take_eq = eq && my_eq < need_eq;
+    if (gt || take_eq) {
+      // ties already taken before me (capped at need_eq) + greater keys before me
+      const unsigned int pos = my_gt + (my_eq < need_eq ? my_eq : need_eq);
+      okeys[pos] = key;
+      oidx[pos] = (uint32_t)(i0 + t);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned int tg = 0, te = 0;
+      for (int ww = 0; ww < kChunkThreads / 64; ++ww) { tg += wsum_gt[ww]; te += wsum_eq[ww]; }
+      sh_taken_gt += tg;
+      sh_taken_eq += te;
+    }
+    __syncthreads();
+  }
+  // padding slots (chunks shorter than kcap): lowest key, sentinel index
+  for (int t = kk + tid; t < kcap; t += kChunkThreads) { okeys[t] = 0u; oidx[t] = 0xffffffffu; }
+}
+
 struct RpnSelArgs {
   const float* head;
   const uint32_t* keys;
+  const uint32_t* kidx;  // anchor index of each key (null: identity)
+  int n_keys;            // keys per image
   int n_img, Hi, Wi, A, head_c, stride_px, level, kmax, slot_off, slots_per_img;
   float ca[3][4];
   float clip_x, clip_y;
@@ -72,18 +168,21 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_kernel(const RpnSelArg
   __shared__ unsigned int wave_sums[kSelThreads / 64];
 
   const int img = blockIdx.x, tid = threadIdx.x;
-  const int n = p.Hi * p.Wi * p.A;
-  const int k = n < p.kmax ? n : p.kmax;
+  const int n = p.n_keys;
+  const int n_anchors = p.Hi * p.Wi * p.A;
+  const int k = n_anchors < p.kmax ? n_anchors : p.kmax;
   int n2 = 1;
   while (n2 < k) n2 <<= 1;
   const uint32_t* keys = p.keys + (long long)img * n;
+  const uint32_t* kidx = p.kidx ? p.kidx + (long long)img * n : nullptr;
+#define DP_AIDX(i) (kidx ? kidx[i] : (uint32_t)(i))
 
   for (int i = tid; i < n2; i += kSelThreads) sel[i] = 0ull;
   if (tid == 0) { sh_count = 0; sh_eq_taken = 0; }
   __syncthreads();
 
   if (n <= p.kmax) {
-    for (int i = tid; i < n; i += kSelThreads) sel[i] = ((unsigned long long)keys[i] << 32) | (uint32_t)(~(uint32_t)i);
+    for (int i = tid; i < n; i += kSelThreads) sel[i] = ((unsigned long long)keys[i] << 32) | (uint32_t)(~DP_AIDX(i));
   } else {
     // ---- radix select (4 x 8 bits, MSB first) of the k-th largest key ----
     uint32_t prefix = 0, mask = 0;
@@ -121,7 +220,7 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_kernel(const RpnSelArg
       const uint32_t key = keys[i];
       if (key > T || (key == T && need_eq == eq_total)) {
         const unsigned int pos = atomicAdd(&sh_count, 1u);
-        sel[pos] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)i);
+        sel[pos] = ((unsigned long long)key << 32) | (uint32_t)(~DP_AIDX(i));
       }
     }
     __syncthreads();
@@ -138,7 +237,7 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_kernel(const RpnSelArg
         unsigned int before = sh_eq_taken;
         for (int ww = 0; ww < w; ++ww) before += wave_sums[ww];
         const unsigned int my = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-        if (f && my < need_eq) sel[base + my] = ((unsigned long long)T << 32) | (uint32_t)(~(uint32_t)i);
+        if (f && my < need_eq) sel[base + my] = ((unsigned long long)T << 32) | (uint32_t)(~DP_AIDX(i));
         __syncthreads();
         if (tid == 0) {
           unsigned int tot = 0;
@@ -334,8 +433,11 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ 
     unsigned long long cur = remv[c];
     unsigned long long km = 0ull;
     const int rows_here = min(64, nvalid - c * 64);
+    const int d_lo = (int)(unsigned)(D & 0xffffffffull), d_hi = (int)(unsigned)(D >> 32);
     for (int j = 0; j < rows_here; ++j) {
-      const unsigned long long dj = __shfl(D, j);  // wave-uniform
+      // v_readlane with a scalar lane index (j is wave-uniform): no LDS round trip per step
+      const unsigned long long dj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(d_hi, j) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readlane(d_lo, j);
       if (!((cur >> j) & 1ull)) {
         km |= (1ull << j);
         cur |= dj;
@@ -358,10 +460,16 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ 
       for (int wd = c + 1 + lane; wd < ncb; wd += 64) {
         unsigned long long acc = remv[wd];
         unsigned long long m = km;
+        const unsigned long long* col = w.mask + (base + (long long)c * 64) * ncb + wd;
         while (m) {
-          const int j = __ffsll((long long)m) - 1;
-          m &= m - 1;
-          acc |= w.mask[(base + c * 64 + j) * ncb + wd];
+          // 4 independent loads per trip (the kept-row list is wave-uniform, so is this control flow)
+          unsigned long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+          int j;
+          j = __ffsll((long long)m) - 1; m &= m - 1; v0 = col[(long long)j * ncb];
+          if (m) { j = __ffsll((long long)m) - 1; m &= m - 1; v1 = col[(long long)j * ncb]; }
+          if (m) { j = __ffsll((long long)m) - 1; m &= m - 1; v2 = col[(long long)j * ncb]; }
+          if (m) { j = __ffsll((long long)m) - 1; m &= m - 1; v3 = col[(long long)j * ncb]; }
+          acc |= (v0 | v1) | (v2 | v3);
         }
         remv[wd] = acc;
       }
@@ -514,7 +622,9 @@ inline int next_pow2(int v) {
 
 // ------------------------------------------------------------------------------------------------------
 extern "C" int64_t dp_rpn_topk_workspace_bytes(int n_img, int Hi, int Wi, int A) {
-  return (int64_t)n_img * Hi * Wi * A * 4;  // compact sortable keys of one level
+  // compact sortable keys of one level (single-stage path) or the (key, index) candidates of the chunked path;
+  // the candidate list is never larger than the key list (kcap <= chunk length), so one bound covers both
+  return (int64_t)n_img * Hi * Wi * A * 8 + 256;
 }
 
 extern "C" int dp_rpn_topk_decode(const dp_rpn_level_params* p, dp_stream_t stream) {
@@ -523,21 +633,34 @@ extern "C" int dp_rpn_topk_decode(const dp_rpn_level_params* p, dp_stream_t stre
   DP_REQUIRE(p->n_img > 0 && p->Hi > 0 && p->Wi > 0 && p->A > 0 && p->A <= 3 && p->head_c >= 5 * p->A, "dp_rpn_topk_decode: bad shape");
   DP_REQUIRE(p->kmax > 0 && p->kmax <= 4096, "dp_rpn_topk_decode: kmax=%d outside (0, 4096]", p->kmax);
   DP_REQUIRE(p->slot_off >= 0 && p->slot_off + p->kmax <= p->slots_per_img, "dp_rpn_topk_decode: slot range");
+  DP_REQUIRE(p->n_img <= 65535, "dp_rpn_topk_decode: n_img");
   const long long n = (long long)p->Hi * p->Wi * p->A;
   DP_REQUIRE(n < (1ll << 30), "dp_rpn_topk_decode: level too large");
   hipStream_t s = as_stream(stream);
-  uint32_t* keys = reinterpret_cast<uint32_t*>(p->workspace);
-  const long long total = n * p->n_img;
-  int g = (int)((total + 255) / 256);
-  if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(rpn_keys_kernel, dim3(g), dim3(256), 0, s, p->head, keys, p->n_img, p->Hi * p->Wi, p->A, p->head_c);
   RpnSelArgs a;
-  a.head = p->head; a.keys = keys; a.n_img = p->n_img; a.Hi = p->Hi; a.Wi = p->Wi; a.A = p->A; a.head_c = p->head_c;
+  a.head = p->head; a.n_img = p->n_img; a.Hi = p->Hi; a.Wi = p->Wi; a.A = p->A; a.head_c = p->head_c;
   a.stride_px = p->stride_px; a.level = p->level; a.kmax = p->kmax; a.slot_off = p->slot_off; a.slots_per_img = p->slots_per_img;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 4; ++j) a.ca[i][j] = p->cell_anchors[i][j];
   a.clip_x = p->clip_x; a.clip_y = p->clip_y;
   a.cand_boxes = p->cand_boxes; a.cand_scores = p->cand_scores; a.cand_level = p->cand_level; a.cand_valid = p->cand_valid;
+  uint32_t* ws = reinterpret_cast<uint32_t*>(p->workspace);
+  if (n >= 2 * kChunk) {
+    // two-stage: per-chunk pre-selection (many workgroups), then one workgroup per image over the candidates
+    const int n_chunks = (int)((n + kChunk - 1) / kChunk);
+    const int kcap = p->kmax < kChunk ? p->kmax : kChunk;
+    uint32_t* ckeys = ws;
+    uint32_t* cidx = ws + (long long)p->n_img * n_chunks * kcap;
+    hipLaunchKernelGGL(rpn_chunk_select_kernel, dim3(n_chunks, p->n_img), dim3(kChunkThreads), 0, s, p->head, p->Hi * p->Wi, p->A, p->head_c,
+                       (int)n, p->kmax, kcap, n_chunks, ckeys, cidx);
+    a.keys = ckeys; a.kidx = cidx; a.n_keys = n_chunks * kcap;
+  } else {
+    const long long total = n * p->n_img;
+    int g = (int)((total + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(rpn_keys_kernel, dim3(g), dim3(256), 0, s, p->head, ws, p->n_img, p->Hi * p->Wi, p->A, p->head_c);
+    a.keys = ws; a.kidx = nullptr; a.n_keys = (int)n;
+  }
   const int k = (int)(n < p->kmax ? n : p->kmax);
   const int n2 = next_pow2(k);
   hipLaunchKernelGGL(rpn_select_kernel, dim3(p->n_img), dim3(kSelThreads), n2 * 8, s, a);

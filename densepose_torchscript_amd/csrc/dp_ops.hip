@@ -151,36 +151,86 @@ __global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, lon
 }
 
 // ---- K18: bilinear x2 + channel split + NHWC -> NCHW (fp32) --------------------------------------------
-__global__ void iuv_upsample_split_kernel(const float* __restrict__ in, int R, int Hs, int Ws, int in_c, int n_coarse, int n_fine,
-                                          float* __restrict__ coarse, float* __restrict__ fine, float* __restrict__ u,
-                                          float* __restrict__ v) {
-  // one thread per (r, c, yo, xo) of the OUTPUT so that NCHW stores are coalesced along x
+// One workgroup per (roi, source row pair i, i+1): the two low-res rows are brought into LDS with coalesced
+// channel-contiguous loads, then the (up to) two output rows 2i+1, 2i+2 that interpolate between them are
+// produced with lanes along x, so every NCHW store instruction writes 256 contiguous bytes.
+constexpr int kIuvMaxRowFloats = 56 * 96;  // Ws * in_c of the largest supported map (S1x: 56 x 80, legacy 28 x 96)
+
+__global__ __launch_bounds__(256) void iuv_upsample_split_kernel(const float* __restrict__ in, int R, int Hs, int Ws, int in_c, int n_coarse,
+                                                                 int n_fine, float* __restrict__ coarse, float* __restrict__ fine,
+                                                                 float* __restrict__ u, float* __restrict__ v) {
+  extern __shared__ __attribute__((aligned(16))) float rows[];  // [2][Ws * in_c]
+  const int r = blockIdx.y;
+  const int i = (int)blockIdx.x - 1;            // source row pair (i, i+1), i in [-1, Hs-1]
+  const int y0 = i < 0 ? 0 : i;
+  const int y1 = i + 1 > Hs - 1 ? Hs - 1 : i + 1;
+  const int rowf = Ws * in_c;
+  const float* src = in + (long long)r * Hs * rowf;
+  for (int t = threadIdx.x * 4; t < rowf; t += 256 * 4) {
+    *reinterpret_cast<float4*>(rows + t) = *reinterpret_cast<const float4*>(src + (long long)y0 * rowf + t);
+    *reinterpret_cast<float4*>(rows + rowf + t) = *reinterpret_cast<const float4*>(src + (long long)y1 * rowf + t);
+  }
+  __syncthreads();
   const int Ho = 2 * Hs, Wo = 2 * Ws, Ctot = n_coarse + 3 * n_fine;
-  const long long total = (long long)R * Ctot * Ho * Wo;
+  const long long hw = (long long)Ho * Wo;
+  // output rows whose bilinear source rows are exactly (y0, y1): yo = 2i+1 (ly = .25) and 2i+2 (ly = .75);
+  // the clamped border rows: yo = 0 <- pair i = -1 (y0 = y1 = 0, ly = 0), yo = Ho-1 <- pair i = Hs-1 (y0 = y1, ly irrelevant)
+  for (int k = 0; k < 2; ++k) {
+    const int yo = 2 * i + 1 + k;
+    if (yo < 0 || yo >= Ho) continue;
+    int yy0, yy1;
+    float ly;
+    bil_src(yo, Hs, yy0, yy1, ly);
+    const float hy = 1.f - ly;
+    for (int t = threadIdx.x; t < Ctot * Wo; t += 256) {
+      const int c = t / Wo, xo = t - c * Wo;
+      int x0, x1;
+      float lx;
+      bil_src(xo, Ws, x0, x1, lx);
+      const float hx = 1.f - lx;
+      const float a = rows[x0 * in_c + c], b = rows[x1 * in_c + c];
+      const float cc = rows[rowf + x0 * in_c + c], d = rows[rowf + x1 * in_c + c];
+      // rows[] holds (y0, y1) = (yy0, yy1) by construction
+      const float val = hy * (hx * a + lx * b) + ly * (hx * cc + lx * d);
+      const long long pix = (long long)yo * Wo + xo;
+      if (c < n_coarse) coarse[((long long)r * n_coarse + c) * hw + pix] = val;
+      else if (c < n_coarse + n_fine) fine[((long long)r * n_fine + (c - n_coarse)) * hw + pix] = val;
+      else if (c < n_coarse + 2 * n_fine) u[((long long)r * n_fine + (c - n_coarse - n_fine)) * hw + pix] = val;
+      else v[((long long)r * n_fine + (c - n_coarse - 2 * n_fine)) * hw + pix] = val;
+    }
+  }
+}
+
+// ---- decoder level merge: out = base + sum_k bilinear_x2(ups[k]) in ONE pass (roi_head.py:71-79) -------------
+template <typename T>
+__global__ void merge_up2x_kernel(const T* __restrict__ base, const T* __restrict__ u0, const T* __restrict__ u1,
+                                  const T* __restrict__ u2, int n_ups, T* __restrict__ out, int N, int H, int W, int C) {
+  // H, W are the LOW-res dims of the ups; base/out are [N, 2H, 2W, C]
+  const int C4 = C >> 2, Ho = 2 * H, Wo = 2 * W;
+  const long long total = (long long)N * Ho * Wo * C4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int xo = (int)(i % Wo);
-    long long t = i / Wo;
+    const int c4 = (int)(i % C4);
+    long long t = i / C4;
+    const int xo = (int)(t % Wo);
+    t /= Wo;
     const int yo = (int)(t % Ho);
-    t /= Ho;
-    const int c = (int)(t % Ctot);
-    const int r = (int)(t / Ctot);
+    const int n = (int)(t / Ho);
     int y0, y1, x0, x1;
     float ly, lx;
-    bil_src(yo, Hs, y0, y1, ly);
-    bil_src(xo, Ws, x0, x1, lx);
-    const float* base = in + (long long)r * Hs * Ws * in_c + c;
-    const float a = base[((long long)y0 * Ws + x0) * in_c];
-    const float b = base[((long long)y0 * Ws + x1) * in_c];
-    const float cc = base[((long long)y1 * Ws + x0) * in_c];
-    const float d = base[((long long)y1 * Ws + x1) * in_c];
-    const float hx = 1.f - lx, hy = 1.f - ly;
-    const float val = hy * (hx * a + lx * b) + ly * (hx * cc + lx * d);
-    const long long hw = (long long)Ho * Wo;
-    const long long pix = (long long)yo * Wo + xo;
-    if (c < n_coarse) coarse[((long long)r * n_coarse + c) * hw + pix] = val;
-    else if (c < n_coarse + n_fine) fine[((long long)r * n_fine + (c - n_coarse)) * hw + pix] = val;
-    else if (c < n_coarse + 2 * n_fine) u[((long long)r * n_fine + (c - n_coarse - n_fine)) * hw + pix] = val;
-    else v[((long long)r * n_fine + (c - n_coarse - 2 * n_fine)) * hw + pix] = val;
+    bil_src(yo, H, y0, y1, ly);
+    bil_src(xo, W, x0, x1, lx);
+    float4 acc = load4(base + i * 4);
+    const long long o00 = (((long long)n * H + y0) * W + x0) * C + c4 * 4, o01 = (((long long)n * H + y0) * W + x1) * C + c4 * 4;
+    const long long o10 = (((long long)n * H + y1) * W + x0) * C + c4 * 4, o11 = (((long long)n * H + y1) * W + x1) * C + c4 * 4;
+    const T* ups[3] = {u0, u1, u2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k < n_ups) {
+        const float4 r = lerp2d(load4(ups[k] + o00), load4(ups[k] + o01), load4(ups[k] + o10), load4(ups[k] + o11), lx, ly);
+        acc.x = acc.x + r.x; acc.y = acc.y + r.y; acc.z = acc.z + r.z; acc.w = acc.w + r.w;
+      }
+    }
+    store4(out + i * 4, acc);
   }
 }
 
@@ -330,10 +380,28 @@ extern "C" int dp_iuv_upsample_split(const dp_iuv_params* p, dp_stream_t stream)
   DP_REQUIRE(p->in && p->coarse && p->fine && p->u && p->v, "dp_iuv_upsample_split: null pointer");
   DP_REQUIRE(p->R > 0 && p->Hs > 0 && p->Ws > 0 && p->n_coarse > 0 && p->n_fine > 0 && p->in_c >= p->n_coarse + 3 * p->n_fine,
              "dp_iuv_upsample_split: bad shape");
-  const long long total = (long long)p->R * (p->n_coarse + 3 * p->n_fine) * 4 * p->Hs * p->Ws;
-  hipLaunchKernelGGL(iuv_upsample_split_kernel, dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), p->in, p->R, p->Hs, p->Ws,
+  DP_REQUIRE(p->in_c % 4 == 0 && p->Ws * p->in_c <= kIuvMaxRowFloats, "dp_iuv_upsample_split: row of %d x %d floats exceeds the LDS staging",
+             p->Ws, p->in_c);
+  DP_REQUIRE(p->R <= 65535, "dp_iuv_upsample_split: R too large");
+  const int lds = 2 * p->Ws * p->in_c * (int)sizeof(float);
+  hipLaunchKernelGGL(iuv_upsample_split_kernel, dim3(p->Hs + 1, p->R), dim3(256), lds, as_stream(stream), p->in, p->R, p->Hs, p->Ws,
                      p->in_c, p->n_coarse, p->n_fine, p->coarse, p->fine, p->u, p->v);
   return dp_check_launch("iuv_upsample_split_kernel");
+}
+
+extern "C" int dp_merge_upsample2x_nhwc(const void* base, const void* const* ups, int n_ups, void* out, int N, int H, int W, int C,
+                                        int dtype, dp_stream_t stream) {
+  DP_REQUIRE(base && ups && out && n_ups >= 1 && n_ups <= 3 && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dp_merge_upsample2x_nhwc: bad args");
+  for (int k = 0; k < n_ups; ++k) DP_REQUIRE(ups[k], "dp_merge_upsample2x_nhwc: null map %d", k);
+  const void* u0 = ups[0];
+  const void* u1 = n_ups > 1 ? ups[1] : nullptr;
+  const void* u2 = n_ups > 2 ? ups[2] : nullptr;
+  const long long total = (long long)N * 4 * H * W * (C / 4);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_DTYPE(dtype,
+                 hipLaunchKernelGGL(merge_up2x_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const float*)base, (const float*)u0, (const float*)u1, (const float*)u2, n_ups, (float*)out, N, H, W, C),
+                 hipLaunchKernelGGL(merge_up2x_kernel<uint16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const uint16_t*)base, (const uint16_t*)u0, (const uint16_t*)u1, (const uint16_t*)u2, n_ups, (uint16_t*)out, N, H, W, C));
+  return dp_check_launch("merge_up2x_kernel");
 }
 
 extern "C" int dp_groupnorm_relu_nhwc(const dp_groupnorm_params* p, dp_stream_t stream) {

@@ -106,7 +106,8 @@ class Engine:
             e0.record()
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
             e1.record()
-            self.prof.append(("conv_igemm_bn64" if layer.cout <= 64 else "conv_igemm_bn128", flops, e0, e1, layer.name))
+            cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_igemm_big_kernel")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
+            self.prof.append((cls, flops, e0, e1, layer.name))
         else:
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
         self.flops_last += flops
@@ -257,26 +258,28 @@ class Engine:
         return det_boxes, det_scores, det_counts
 
     def decoder(self, feats):
+        """roi_head.py:71-79: x = head(p2) + head(p3) + head(p4) + head(p5), each head ending in a bilinear x2 except p2's;
+        the three final upsamples and the level sum run as ONE pass (dp_merge_upsample2x_nhwc, same fp32 summation order)."""
         Ls = self.model.layers
-        acc = None
+        base, lows = None, []
         for lvl, nconv in decoder_layout(self.cfg):
             t = feats[lvl]
             for k in range(nconv):
                 t = self.conv(Ls["roi_heads.decoder.%s.%d" % (lvl, 2 * k)], t, relu=True)
                 if lvl == "p2":
-                    acc = t
-                    continue
-                last = (k == nconv - 1)
-                if last:
-                    assert 2 * t.H == acc.H and 2 * t.W == acc.W and t.C == acc.C
-                    L.check(self.lib.dp_upsample_bilinear2x_nhwc(t.t.data_ptr(), acc.t.data_ptr(), t.N, t.H, t.W, t.C, 1, self.dt,
-                                                                 self._stream()), "upsample+add")
-                else:
+                    base = t
+                elif k < nconv - 1:
                     up = self._empty((t.N, 2 * t.H, 2 * t.W, t.C))
                     L.check(self.lib.dp_upsample_bilinear2x_nhwc(t.t.data_ptr(), up.data_ptr(), t.N, t.H, t.W, t.C, 0, self.dt,
                                                                  self._stream()), "upsample")
                     t = Act(up, t.N, 2 * t.H, 2 * t.W, t.C)
-        return self.conv(Ls["decoder_predictor"], acc)
+                else:
+                    assert 2 * t.H == base.H and 2 * t.W == base.W and t.C == base.C
+                    lows.append(t)
+        arr = (C.c_void_p * len(lows))(*[t.t.data_ptr() for t in lows])
+        L.check(self.lib.dp_merge_upsample2x_nhwc(base.t.data_ptr(), arr, len(lows), base.t.data_ptr(), base.N, lows[0].H, lows[0].W,
+                                                  base.C, self.dt, self._stream()), "dp_merge_upsample2x_nhwc")
+        return self.conv(Ls["decoder_predictor"], base)
 
     def groupnorm(self, x_t, R, HW, Cc, c_stride, c_off, gn, relu=True):
         p = L.GroupNormParams()

@@ -100,10 +100,12 @@ SYMBOLS = {
     "dp_last_error": (C.c_char_p, []),
     "dp_preprocess_u8": (c_int, [C.POINTER(PreprocessParams), c_void_p]),
     "dp_conv2d_nhwc": (c_int, [C.POINTER(ConvParams), c_void_p]),
+    "dp_conv2d_kernel_class": (c_int, [C.POINTER(ConvParams)]),
     "dp_maxpool3x3s2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_subsample2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_upsample_bilinear2x_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_add_nhwc": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "dp_merge_upsample2x_nhwc": (c_int, [c_void_p, C.POINTER(c_void_p), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_rpn_topk_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
     "dp_rpn_topk_decode": (c_int, [C.POINTER(RpnLevelParams), c_void_p]),
     "dp_nms_workspace_bytes": (c_i64, [c_int, c_int]),

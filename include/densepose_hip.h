@@ -82,6 +82,9 @@ typedef struct {
   int32_t hi_off, wi_off; /* input pixel of output (ho,wo), tap (dy,dx): (ho*stride + hi_off + dy, wo*stride + wi_off + dx) */
 } dp_conv_params;
 int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
+/* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = 128x64 tile, 1 = 128x128 tile, 2 = 256x256 LDS-ring tile
+ * (profiling / roofline bookkeeping only) */
+int dp_conv2d_kernel_class(const dp_conv_params* p);
 
 /* K3  resnet.py:353  F.max_pool2d(k=3, s=2, p=1), NHWC */
 int dp_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, dp_stream_t stream);
@@ -92,6 +95,10 @@ int dp_subsample2_nhwc(const void* in, void* out, int N, int H, int W, int C, in
 /* K14 roi_head.py:63,71-79  out = (accumulate ? out : 0) + bilinear_x2(in), align_corners=False */
 int dp_upsample_bilinear2x_nhwc(const void* in, void* out, int N, int H, int W, int C, int accumulate, int dtype,
                                 dp_stream_t stream);
+/* K14 roi_head.py:71-79  out = base + sum_k bilinear_x2(ups[k]), k < n_ups <= 3, summed in list order in fp32:
+ * the decoder's level sum in one pass. ups are [N,H,W,C], base/out [N,2H,2W,C] (out may alias base). */
+int dp_merge_upsample2x_nhwc(const void* base, const void* const* ups, int n_ups, void* out, int N, int H, int W, int C,
+                             int dtype, dp_stream_t stream);
 /* elementwise out += in (decoder level sum when no upsample is involved) */
 int dp_add_nhwc(const void* in, void* out, int64_t count, int dtype, dp_stream_t stream);
 

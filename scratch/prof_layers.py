@@ -20,7 +20,7 @@ eng.prof = None
 tot = sum(r[1] for r in rows.values())
 print("wall %.2f ms, conv total %.2f ms" % (wall * 1e3, tot))
 for name, (fl, ms, n, cls) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:45]:
-    print("%-52s %s n=%d %8.3f ms %7.1f GF %7.1f TF/s" % (name[-52:], cls[-5:], n, ms, fl / 1e9, fl / ms / 1e9))
+    print("%-52s %s n=%d %8.3f ms %7.1f GF %7.1f TF/s" % (name[-52:], cls[-12:], n, ms, fl / 1e9, fl / ms / 1e9))
 # non-conv time: whole-step stage timing with events
 ev = lambda: torch.cuda.Event(enable_timing=True)
 import densepose_torchscript_amd.engine as E

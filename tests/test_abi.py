@@ -45,7 +45,7 @@ def test_argument_validation_without_gpu(built):
     q = built.NmsParams()
     assert lib.dp_batched_nms(ctypes.byref(q), None) == -1
     assert lib.dp_nms_workspace_bytes(2, 1000) > 2 * 1000 * 16 * 8
-    assert lib.dp_rpn_topk_workspace_bytes(8, 200, 336, 3) == 8 * 200 * 336 * 3 * 4
+    assert lib.dp_rpn_topk_workspace_bytes(8, 200, 336, 3) >= 8 * 200 * 336 * 3 * 4
 
 
 def test_struct_layout_matches_c(built, tmp_path):

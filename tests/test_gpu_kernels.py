@@ -43,6 +43,24 @@ CONV_CASES = [
 ]
 
 
+BIG_CASES = [
+    # shapes the large-tile (256x256, LDS ring) kernel is legal for; DP_CONV_BIG=1 forces it even for few tiles
+    (2, 256, 13, 21, 256, 3, 1, 1, 1, False, False),
+    (1, 512, 28, 28, 512, 3, 1, 1, 1, True, False),
+    (3, 64, 20, 37, 256, 1, 1, 0, 1, True, True),
+    (1, 256, 40, 56, 256, 3, 1, 1, 1, True, False),
+    (2, 1024, 9, 11, 512, 1, 2, 0, 1, False, False),
+    (1, 32, 30, 30, 256, 3, 1, 2, 2, False, False),
+]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", BIG_CASES)
+def test_conv2d_large_tile_kernel(eng, dt, case, monkeypatch):
+    monkeypatch.setenv("DP_CONV_BIG", "1")
+    test_conv2d_matches_torch(eng, dt, case)
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_matches_torch(eng, dt, case):
@@ -229,19 +247,20 @@ def test_roi_align_matches_oracle(eng, dt, multi):
         assert torch.allclose(got[i, : counts[i]], ref, atol=tol), (got[i, : counts[i]] - ref).abs().max()
 
 
-def test_rpn_topk_decode_matches_oracle(eng):
+@pytest.mark.parametrize("Hi,Wi", [(48, 80), (100, 150)])   # 11,520 anchors: single-stage select ; 45,000: chunked two-stage select
+def test_rpn_topk_decode_matches_oracle(eng, Hi, Wi):
     from densepose_torchscript_amd import lib as L
     from oracle.ref_cpu import OracleModel
     e = eng["fp32"]
     g = torch.Generator().manual_seed(9)
-    n_img, Hi, Wi, A = 2, 48, 80, 3   # 11520 anchors > kmax -> radix select path
+    n_img, A = 2, 3
     head = torch.randn((n_img, Hi, Wi, 16), generator=g)
     head[..., 3:15] *= 0.3
     head[0, 0, 0, 5] = float("nan")     # a NaN delta -> that anchor must be dropped if selected
     head[0, 0, 0, 0] = 50.0             # ... and it IS selected
     head[1, 3, 4, 1] = 40.0
     head[1, 3, 4, 9] = 20.0             # dw above the clamp
-    head[1, :, :5, 2] = 2.2             # 240 exact ties that straddle the top-k boundary
+    head[1, :, :5, 2] = 2.2 if Hi == 48 else 2.75   # exact ties (240 / 500 anchors) that straddle the top-k boundary
     kmax, stride = 200, 8
     cell = [[-22.6, -11.3, 22.6, 11.3], [-16.0, -16.0, 16.0, 16.0], [-11.3, -22.6, 11.3, 22.6]]
     dev = e.device
@@ -290,10 +309,18 @@ def test_rpn_topk_decode_matches_oracle(eng):
         assert torch.allclose(ours_boxes[m], ref_c[m], atol=1e-3, rtol=1e-5)
         assert int(cl[i, kmax:].min()) == 1 and int(cl[i, kmax:].max()) == 1
     # tie handling: exactly the needed number of tied entries is taken
+    tv = 2.2 if Hi == 48 else 2.75
     lg = head[1, :, :, :3].reshape(-1)
-    n_gt = int((lg > 2.2).sum())
-    assert n_gt < kmax < n_gt + int((lg == 2.2).sum())
-    assert int((cs[1, kmax:].cpu() == 2.2).sum()) == kmax - n_gt
+    n_gt = int((lg > tv).sum())
+    assert n_gt < kmax < n_gt + int((lg == tv).sum())
+    assert int((cs[1, kmax:].cpu() == tv).sum()) == kmax - n_gt
+    # the tied survivors are the ones with the LOWEST anchor indices (x < 5 columns scanned row-major): rows y = 0.. first
+    tied = (cs[1, kmax:].cpu() == tv)
+    got_boxes = cb[1, kmax:].cpu()[tied]
+    tie_idx = torch.nonzero(lg == tv)[:, 0][: kmax - n_gt]
+    props1 = OracleModel.apply_deltas(head[1, :, :, 3:15].reshape(-1, 4), anchors, (1.0, 1.0, 1.0, 1.0))
+    exp = OracleModel.clip_boxes(props1[tie_idx], (500.0, 300.0))
+    assert torch.allclose(got_boxes, exp, atol=1e-3, rtol=1e-5)
 
 
 def test_box_decode_and_groupnorm_gap(eng):
