@@ -43,6 +43,8 @@ struct ConvArgs {
   int N, H, W, Cin, Ho, Wo, Cout, Kpad, stride, hi_off, wi_off, relu, rshift, out_f32;
   long long osN, osH, osW, rsN, rsH, rsW;
   int M, tiles_n, n_ktiles, HoWo, n_tiles;
+  unsigned in_bytes, w_bytes;   // buffer-resource extents (ring kernels)
+  int ntaps, out_linear, res_linear;
 };
 
 __device__ __forceinline__ int swz(int r) { return (-(r >> 2)) & 3; }
@@ -103,12 +105,16 @@ __device__ __forceinline__ void drain_rows(const ConvArgs& p, const float* lds, 
     f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + r * COLS + c1);
     v0 += b0;
     v1 += b1;
-    const int n = m / p.HoWo;
-    const int rem = m - n * p.HoWo;
-    const int ho = rem / p.Wo;
-    const int wo = rem - ho * p.Wo;
+    // plain NHWC tensors: element offset = m * pixel stride, no (n, ho, wo) decomposition (two integer divisions)
+    int n = 0, ho = 0, wo = 0;
+    if (!p.out_linear || (res && !p.res_linear)) {
+      n = m / p.HoWo;
+      const int rem = m - n * p.HoWo;
+      ho = rem / p.Wo;
+      wo = rem - ho * p.Wo;
+    }
     if (res) {
-      const long long rb = n * p.rsN + (ho >> p.rshift) * p.rsH + (wo >> p.rshift) * p.rsW + co;
+      const long long rb = (p.res_linear ? (long long)m * p.rsW : n * p.rsN + (ho >> p.rshift) * p.rsH + (wo >> p.rshift) * p.rsW) + co;
       const float4 ra = load4(res + rb), rc = load4(res + rb + 4);
       v0[0] += ra.x; v0[1] += ra.y; v0[2] += ra.z; v0[3] += ra.w;
       v1[0] += rc.x; v1[1] += rc.y; v1[2] += rc.z; v1[3] += rc.w;
@@ -117,7 +123,7 @@ __device__ __forceinline__ void drain_rows(const ConvArgs& p, const float* lds, 
 #pragma unroll
       for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
     }
-    const long long ob = n * p.osN + ho * p.osH + wo * p.osW + co;
+    const long long ob = (p.out_linear ? (long long)m * p.osW : n * p.osN + ho * p.osH + wo * p.osW) + co;
     if (p.out_f32 || sizeof(T) == 4) {
       float* o = reinterpret_cast<float*>(p.out) + ob;
       *reinterpret_cast<f32x4*>(o) = v0;
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs 
     _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                                          \
       _Pragma("unroll") for (int i = 0; i < A_GROUPS; ++i) {                                                      \
         const int hi = a_hi0[i] + (EN)[pl][0], wi = a_wi0[i] + (EN)[pl][1];                                       \
-        const bool ok = (EN)[pl][3] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;              \
+        const bool ok = ((EN)[pl][3] & 1) && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;              \
         const long long off = (long long)(a_pix[i] + hi * p.W + wi) * p.Cin + (EN)[pl][2];                        \
         const T* src = ok ? (in + off) : zsrc;                                                                    \
         __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(src), DP_LDS_PTR(lds_a + (BUF_IDX) * BUF + pl * A_PLANE + i * 1024), 16, 0, 0); \
@@ -300,19 +306,16 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs 
 #undef DP_STAGE_TILE
 
 // =====================================================================================================
-// Large-tile variant for the layers that carry most of the FLOPs (3x3 / 1x1 with Cin*esize % 64 == 0, Cout % 256 == 0,
-// thousands of pixel tiles): 256 pixels x 256 couts per workgroup, 8 waves (64 couts x 128 pixels each, 128 accumulator
-// VGPRs), K consumed in 64-byte planes through a 4-slot LDS ring (4 x 32 KiB) filled by global_load_lds.
-// Three planes stay in flight behind a COUNTED s_waitcnt vmcnt(N) + raw s_barrier (a plain __syncthreads() would drain
-// them), so HBM/L2 latency is covered by ~3 x 32 MFMAs per wave; bytes per FLOP are half those of the 128 x 128 tile.
-// A 64-byte plane lies inside one tap, so the tap-table entry is wave-uniform and fetched with scalar loads (no VMEM
-// traffic besides the LDS-DMA itself, which keeps the vmcnt arithmetic exact).
+// LDS-ring kernels for the layers that carry the FLOPs (Cin*esize % 64 == 0, i.e. a 64-byte K plane lies inside
+// one tap): K is consumed in 64-byte planes through a 4-slot LDS ring filled by global_load_lds; up to two planes stay
+// in flight behind a COUNTED s_waitcnt vmcnt(N) + raw s_barrier (a plain __syncthreads() would drain them) while the
+// MFMAs of the current plane run on fragments that were read from LDS during the previous plane's MFMAs (register
+// double buffering). The tap-table entry of a plane is wave-uniform and fetched with scalar loads, so the only VMEM
+// traffic of the loop is the LDS-DMA itself and the vmcnt arithmetic is exact.
+//   WC = 4, TP = 8 : 256 pixels x 256 couts, 8 waves (64 couts x 128 pixels each), 4 x 32 KiB ring, 1 workgroup / CU
+//   WC = 2, TP = 4 : 128 pixels x 128 couts, 4 waves (64 x 64 each),               4 x 16 KiB ring, 2 workgroups / CU
 // =====================================================================================================
-constexpr int kBigThreads = 512;
-constexpr int kBigM = 256, kBigN = 256;
-constexpr int kBigPlane = 256 * 64;          // bytes of one operand plane
-constexpr int kBigSlot = 2 * kBigPlane;      // A plane + B plane
-constexpr int kBigRing = 4;
+constexpr int kRing = 4;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -321,12 +324,18 @@ __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
-template <typename T>
-__global__ __launch_bounds__(kBigThreads, 2) void conv_igemm_big_kernel(const ConvArgs p) {
+template <typename T, int WC, int TP>
+__global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArgs p) {
   constexpr int ES = sizeof(T);
   constexpr int CH = 16 / ES;
-  constexpr int PE = 64 / ES;  // elements of K per plane
-  constexpr int TC = 4, TP = 8;
+  constexpr int PE = 64 / ES;             // elements of K per plane
+  constexpr int TC = 4;
+  constexpr int NW = WC * 2;              // waves
+  constexpr int NT = NW * 64;
+  constexpr int BM = 2 * TP * 16;         // pixels
+  constexpr int BN = WC * 64;             // couts
+  constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, SLOT = A_PLANE + B_PLANE;
+  static_assert(BM / 16 / NW == 2 && BN / 16 / NW == 2, "each wave stages two 16-row pieces of each operand plane");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -338,56 +347,62 @@ __global__ __launch_bounds__(kBigThreads, 2) void conv_igemm_big_kernel(const Co
   }
   const int mt = tile / p.tiles_n;
   const int nt = tile - mt * p.tiles_n;
-  const int m0 = mt * kBigM;
-  const int n0 = nt * kBigN;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wc = wave & 3;   // cout quarter (64)
-  const int wp = wave >> 2;  // pixel half (128)
+  const int wc = wave % WC;   // cout block (64)
+  const int wp = wave / WC;   // pixel half
 
   const int srow = lane >> 2;
   const int scc = (lane & 3) ^ swz(srow);
 
-  // per-lane descriptors of the two pixel rows this lane stages (rows 32*wave + 16*i + srow of the tile)
-  int a_hi0[2], a_wi0[2], a_off[2];
+  // constant address space: the only way to get s_load (a vector load here would sit in vmcnt and drain the ring)
+  const __attribute__((address_space(4))) i32x4* ktab_c = (const __attribute__((address_space(4))) i32x4*)p.ktab;
+
+  // per-lane descriptors of the two pixel rows this lane stages (rows 32*wave + 16*i + srow of the tile):
+  // byte offset of (row, tap (0,0), this lane's chunk) - possibly "virtual" at the border - and a bit mask of the taps
+  // that fall inside the image for this row. Per plane the staging then costs one add + one select per load:
+  // out-of-image / K-padding chunks get an out-of-range buffer offset, for which the hardware returns zeros.
+  int a_boff[2];
+  unsigned a_okm[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + wave * 32 + i * 16 + srow;
+    a_okm[i] = 0u;
+    a_boff[i] = 0;
     if (m < p.M) {
       const int n = m / p.HoWo;
       const int rem = m - n * p.HoWo;
       const int ho = rem / p.Wo;
       const int wo = rem - ho * p.Wo;
-      a_hi0[i] = ho * p.stride + p.hi_off;
-      a_wi0[i] = wo * p.stride + p.wi_off;
-      a_off[i] = ((n * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.Cin + scc * CH;  // may be "virtual" (negative) at the border
-    } else {
-      a_hi0[i] = -(1 << 28);
-      a_wi0[i] = 0;
-      a_off[i] = 0;
+      const int hi0 = ho * p.stride + p.hi_off, wi0 = wo * p.stride + p.wi_off;
+      a_boff[i] = (((n * p.H + hi0) * p.W + wi0) * p.Cin + scc * CH) * ES;
+      for (int t = 0; t < p.ntaps; ++t) {
+        const i32x4 e = ktab_c[t * 4];  // planes 0..ntaps-1 enumerate the taps (channel-block-major packing)
+        if ((unsigned)(hi0 + e[0]) < (unsigned)p.H && (unsigned)(wi0 + e[1]) < (unsigned)p.W) a_okm[i] |= 1u << t;
+      }
     }
   }
-  const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
-  const T* __restrict__ wgt = reinterpret_cast<const T*>(p.weight) + (long long)(n0 + wave * 32 + srow) * p.Kpad + scc * CH;
-  const T* __restrict__ zsrc = reinterpret_cast<const T*>(&g_zero16);
+  const int w_boff = ((n0 + wave * 32 + srow) * p.Kpad + scc * CH) * ES;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
   unsigned char* const lds_st = smem + wave * 2048;  // this wave's 2 KiB of each plane
-  // constant address space: the only way to get s_load (a vector load here would sit in vmcnt and drain the ring)
-  const __attribute__((address_space(4))) i32x4* ktab_c = (const __attribute__((address_space(4))) i32x4*)p.ktab;
 
-#define DP_BIG_STAGE(S_IDX, E)                                                                                     \
+#define DP_RING_STAGE(S_IDX, E)                                                                                    \
   {                                                                                                                \
-    const int tap_off = ((E)[0] * p.W + (E)[1]) * p.Cin + (E)[2];                                                  \
-    unsigned char* dst = lds_st + ((S_IDX) & (kBigRing - 1)) * kBigSlot;                                           \
+    const int tap_boff = (((E)[0] * p.W + (E)[1]) * p.Cin + (E)[2]) * ES;                                          \
+    const unsigned tapbit = ((E)[3] & 1) ? (1u << ((E)[3] >> 8)) : 0u;                                             \
+    unsigned char* dst = lds_st + ((S_IDX) & (kRing - 1)) * SLOT;                                                  \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
-      const bool ok = (E)[3] && (unsigned)(a_hi0[i] + (E)[0]) < (unsigned)p.H && (unsigned)(a_wi0[i] + (E)[1]) < (unsigned)p.W; \
-      const T* src = ok ? (in + (a_off[i] + tap_off)) : zsrc;                                                      \
-      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(src), DP_LDS_PTR(dst + i * 1024), 16, 0, 0);                  \
+      const int off = (a_okm[i] & tapbit) ? (a_boff[i] + tap_boff) : (int)0x80000000;                              \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(dst + i * 1024), 16, off, 0, 0, 0);               \
     }                                                                                                              \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
-      const T* wsrc = wgt + (long long)(16 * i) * p.Kpad + (S_IDX) * PE;                                           \
-      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(wsrc), DP_LDS_PTR(dst + kBigPlane + i * 1024), 16, 0, 0);     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DP_LDS_PTR(dst + A_PLANE + i * 1024), 16,                     \
+                                               w_boff + (16 * i * p.Kpad + (S_IDX) * PE) * ES, 0, 0, 0);           \
     }                                                                                                              \
   }
 
@@ -401,68 +416,91 @@ __global__ __launch_bounds__(kBigThreads, 2) void conv_igemm_big_kernel(const Co
   const int fq = lane >> 4;
   const int rd_off = fr * 64 + ((fq ^ swz(fr)) << 4);
   const unsigned char* const rd_a = smem + (wp * TP * 16) * 64 + rd_off;
-  const unsigned char* const rd_b = smem + kBigPlane + (wc * TC * 16) * 64 + rd_off;
+  const unsigned char* const rd_b = smem + A_PLANE + (wc * TC * 16) * 64 + rd_off;
+
+#define DP_RING_READ(S_IDX, FP, FC)                                                                                \
+  {                                                                                                                \
+    const int slot_ = ((S_IDX) & (kRing - 1)) * SLOT;                                                              \
+    _Pragma("unroll") for (int i = 0; i < TC; ++i) (FC)[i] = *reinterpret_cast<const u32x4*>(rd_b + slot_ + i * 16 * 64); \
+    _Pragma("unroll") for (int j = 0; j < TP; ++j) (FP)[j] = *reinterpret_cast<const u32x4*>(rd_a + slot_ + j * 16 * 64); \
+  }
+
+// one K plane: make plane S+1 visible, refill the slot of plane S-1 with plane S+3, prefetch the fragments of plane S+1
+// into the other register set, then run the MFMAs of plane S on the current set
+#define DP_RING_STEP(S_IDX, FP_CUR, FC_CUR, FP_NXT, FC_NXT)                                                        \
+  {                                                                                                                \
+    if ((S_IDX) + 1 < ns) {                                                                                        \
+      if ((S_IDX) + 2 < ns) wait_vmcnt<4>(); else wait_vmcnt<0>();   /* only plane S+2 may still be in flight */   \
+      __builtin_amdgcn_s_barrier();                                                                                \
+      if ((S_IDX) + 3 < ns) {                                                                                      \
+        DP_RING_STAGE((S_IDX) + 3, e_nx);                                                                          \
+        e_nx = ktab_c[((S_IDX) + 4 < ns ? (S_IDX) + 4 : (S_IDX) + 3) * 4];                                         \
+      }                                                                                                            \
+      DP_RING_READ((S_IDX) + 1, FP_NXT, FC_NXT);                                                                   \
+    }                                                                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TC; ++i)                                                                 \
+      _Pragma("unroll") for (int j = 0; j < TP; ++j) Mma<T>::run((FC_CUR)[i], (FP_CUR)[j], acc[i][j]);             \
+    __builtin_amdgcn_s_setprio(0);                                                                                 \
+  }
 
   const int ns = p.n_ktiles * 2;  // number of 64-byte planes along K
   {
     const i32x4 t0 = ktab_c[0];
-    DP_BIG_STAGE(0, t0);
-    if (ns > 1) { const i32x4 t1 = ktab_c[4]; DP_BIG_STAGE(1, t1); }
-    if (ns > 2) { const i32x4 t2 = ktab_c[8]; DP_BIG_STAGE(2, t2); }
+    DP_RING_STAGE(0, t0);
+    if (ns > 1) { const i32x4 t1 = ktab_c[4]; DP_RING_STAGE(1, t1); }
+    if (ns > 2) { const i32x4 t2 = ktab_c[8]; DP_RING_STAGE(2, t2); }
   }
   // tap entry (wave-uniform, scalar load) of the plane staged in the NEXT step: fetched one step ahead of its use
   i32x4 e_nx = ktab_c[(ns > 3 ? 3 : 0) * 4];
 
-  for (int s = 0; s < ns; ++s) {
-    // plane s has landed once at most the younger planes' LDS-DMAs (4 per plane per wave) are outstanding
-    if (s + 2 < ns) wait_vmcnt<8>();
-    else if (s + 1 < ns) wait_vmcnt<4>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    const int slot = (s & (kBigRing - 1)) * kBigSlot;
-    u32x4 fp[TP], fc[TC];
-#pragma unroll
-    for (int i = 0; i < TC; ++i) fc[i] = *reinterpret_cast<const u32x4*>(rd_b + slot + i * 16 * 64);
-#pragma unroll
-    for (int j = 0; j < TP; ++j) fp[j] = *reinterpret_cast<const u32x4*>(rd_a + slot + j * 16 * 64);
-    // refill the slot that every wave finished reading before this barrier (it held plane s-1)
-    if (s + 3 < ns) {
-      DP_BIG_STAGE(s + 3, e_nx);
-      e_nx = ktab_c[(s + 4 < ns ? s + 4 : s + 3) * 4];
-    }
-#pragma unroll
-    for (int i = 0; i < TC; ++i)
-#pragma unroll
-      for (int j = 0; j < TP; ++j) Mma<T>::run(fc[i], fp[j], acc[i][j]);
+  u32x4 fpA[TP], fcA[TC], fpB[TP], fcB[TC];
+  // plane 0 landed once at most planes 1 and 2 (4 LDS-DMAs per plane per wave) are outstanding
+  if (ns > 2) wait_vmcnt<8>();
+  else if (ns > 1) wait_vmcnt<4>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  DP_RING_READ(0, fpA, fcA);
+
+  for (int s = 0; s < ns; s += 2) {
+    DP_RING_STEP(s, fpA, fcA, fpB, fcB);
+    if (s + 1 < ns) DP_RING_STEP(s + 1, fpB, fcB, fpA, fcA);
   }
 
-  // ---- epilogue: two passes (pixel halves) through the 128 KiB of LDS as an fp32 [128][256] staging tile ----
+  // ---- epilogue through the ring's LDS as an fp32 staging tile of (ring bytes / (BN*4)) pixel rows per pass ----
   float* const stage = reinterpret_cast<float*>(smem);
+  constexpr int ROWS_PER_PASS = kRing * SLOT / (BN * 4);     // 128 for both shapes
+  constexpr int PASSES = BM / ROWS_PER_PASS;                 // 2 (256-pixel tile) or 1 (128-pixel tile)
+  static_assert(ROWS_PER_PASS == 128 && (PASSES == 1 || PASSES == 2), "staging geometry");
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    __syncthreads();  // operands (half 0) / previous staging tile (half 1) no longer needed
-    if (wp == half) {
+  for (int pass = 0; pass < PASSES; ++pass) {
+    __syncthreads();  // operands (pass 0) / previous staging tile (pass 1) no longer needed
+    if (PASSES == 1 || wp == pass) {
+      const int r0 = PASSES == 1 ? wp * TP * 16 : 0;
 #pragma unroll
       for (int j = 0; j < TP; ++j)
 #pragma unroll
-        for (int i = 0; i < TC; ++i) park_acc<kBigN>(stage, j * 16 + fr, wc * TC * 16 + i * 16 + fq * 4, acc[i][j]);
+        for (int i = 0; i < TC; ++i) park_acc<BN>(stage, r0 + j * 16 + fr, wc * TC * 16 + i * 16 + fq * 4, acc[i][j]);
     }
     __syncthreads();
-    drain_rows<T, kBigN, kBigThreads>(p, stage, 128, m0 + half * 128, n0, tid);
+    drain_rows<T, BN, NT>(p, stage, ROWS_PER_PASS, m0 + pass * ROWS_PER_PASS, n0, tid);
   }
 }
-#undef DP_BIG_STAGE
+#undef DP_RING_STAGE
+#undef DP_RING_READ
+#undef DP_RING_STEP
 
-template <typename T>
-int launch_conv_big(const ConvArgs& a, hipStream_t stream) {
-  constexpr int lds = kBigRing * kBigSlot;
+template <typename T, int WC, int TP>
+int launch_conv_ring(const ConvArgs& a, hipStream_t stream) {
+  constexpr int BM = 2 * TP * 16, BN = WC * 64;
+  constexpr int lds = kRing * (BM + BN) * 64;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_big_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<T, WC, TP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_big_kernel<T>), dim3(a.n_tiles), dim3(kBigThreads), lds, stream, a);
-  return dp_check_launch("conv_igemm_big_kernel");
+  hipLaunchKernelGGL((conv_ring_kernel<T, WC, TP>), dim3(a.n_tiles), dim3(WC * 2 * 64), lds, stream, a);
+  return dp_check_launch("conv_ring_kernel");
 }
 
 template <typename T, int BN, int NPL>
@@ -490,10 +528,11 @@ int launch_conv_k(const ConvArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-// Kernel choice: estimated speed = plateau speed of the tile shape x wave-quantisation efficiency on this chip
-// (workgroups / (CUs x resident workgroups per CU), rounded up to whole rounds). Plateau ratios measured on MI355X
-// (profiles/): large tile ~1.17x the 128x128 tile when both fill the chip.
-enum { DP_CONV_K64 = 0, DP_CONV_K128 = 1, DP_CONV_BIG = 2 };
+// Kernel choice (measured on MI355X, profiles/): the LDS-ring kernels need a 64-byte K plane to lie inside one tap;
+// the 256x256 ring tile is ~1.15x the 128x128 ring tile when both fill the chip, so the shape is picked by
+// wave-quantisation efficiency (workgroups / (CUs x resident workgroups per CU), rounded up to whole rounds);
+// short-K layers are HBM/latency bound and run on the generic kernel with 64-byte steps (4 workgroups per CU).
+enum { DP_CONV_K64 = 0, DP_CONV_K128 = 1, DP_CONV_RING256 = 2, DP_CONV_RING128 = 3 };
 
 static int num_cus() {
   static int n = 0;
@@ -511,18 +550,31 @@ static int num_cus() {
 static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   const int es = p->dtype == DP_F32 ? 4 : 2;
   if (p->Cout <= 64) return DP_CONV_K64;
-  const bool legal = (p->Cin * es) % 64 == 0 && p->Cout % kBigN == 0 && p->Cout_w % kBigN == 0;
-  const char* fe = getenv("DP_CONV_BIG");  // test/debug knob - 0: never, 1: whenever legal
-  if (fe) return (legal && atoi(fe) == 1) ? DP_CONV_BIG : DP_CONV_K128;
-  if (!legal) return DP_CONV_K128;
-  // short-K layers are HBM/latency bound: many small resident workgroups beat the deep ring (which needs K to fill)
-  if ((long long)p->Kpad * es < 1024) return DP_CONV_K128;
+  // ring kernels: a 64-byte plane inside one tap, <= 32 taps (per-row tap validity is a bit mask), tensors addressable
+  // through 32-bit buffer offsets
+  const bool ring_ok = (p->Cin * es) % 64 == 0 && p->ntaps >= 1 && p->ntaps <= 32 &&
+                       (long long)p->N * p->H * p->W * p->Cin * es < (1ll << 31) && (long long)p->Cout_w * p->Kpad * es < (1ll << 31);
+  const bool big_ok = ring_ok && p->Cout % 256 == 0 && p->Cout_w % 256 == 0;
+  const char* fe = getenv("DP_CONV_BIG");  // test/debug knob - 0: generic only, 1: 256x256 ring whenever legal, 2: 128x128 ring whenever legal
+  if (fe) {
+    const int f = atoi(fe);
+    if (f == 1 && big_ok) return DP_CONV_RING256;
+    if (f == 2 && ring_ok) return DP_CONV_RING128;
+    return DP_CONV_K128;
+  }
+  if (!ring_ok) return DP_CONV_K128;
+  if ((long long)p->Kpad * es < 1024) return DP_CONV_K128;   // short K: see above
   const double cus = (double)num_cus();
-  const double tb = (double)((M + kBigM - 1) / kBigM) * (p->Cout / kBigN);
-  const double ts = (double)((M + kBM - 1) / kBM) * ((p->Cout + 127) / 128);
-  const double rb = tb / cus, rs = ts / (2.0 * cus);               // rounds (1 resp. 2 workgroups resident per CU)
-  const double eff_b = rb / (double)(long long)(rb + 0.999999), eff_s = rs / (double)(long long)(rs + 0.999999);
-  return (1.17 * eff_b > eff_s) ? DP_CONV_BIG : DP_CONV_K128;
+  const double ts = (double)((M + 127) / 128) * ((p->Cout + 127) / 128);
+  const double rs = ts / (2.0 * cus);
+  const double eff_s = rs / (double)(long long)(rs + 0.999999);
+  if (big_ok) {
+    const double tb = (double)((M + 255) / 256) * (p->Cout / 256);
+    const double rb = tb / cus;
+    const double eff_b = rb / (double)(long long)(rb + 0.999999);
+    if (1.15 * eff_b > eff_s) return DP_CONV_RING256;
+  }
+  return DP_CONV_RING128;
 }
 
 extern "C" int dp_conv2d_kernel_class(const dp_conv_params* p) {
@@ -551,12 +603,22 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   a.stride = p->stride; a.hi_off = p->hi_off; a.wi_off = p->wi_off; a.relu = p->relu; a.rshift = p->rshift; a.out_f32 = p->out_f32;
   a.osN = p->osN; a.osH = p->osH; a.osW = p->osW; a.rsN = p->rsN; a.rsH = p->rsH; a.rsW = p->rsW;
   a.M = (int)M; a.HoWo = p->Ho * p->Wo; a.n_ktiles = p->Kpad * es / kKB;
+  a.in_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cin * es);
+  a.w_bytes = (unsigned)((long long)p->Cout_w * p->Kpad * es);
+  a.ntaps = p->ntaps;
+  a.out_linear = (p->osH == (long long)p->Wo * p->osW && p->osN == (long long)p->Ho * p->osH) ? 1 : 0;
+  a.res_linear = (p->residual && p->rshift == 0 && p->rsH == (long long)p->Wo * p->rsW && p->rsN == (long long)p->Ho * p->rsH) ? 1 : 0;
   hipStream_t s = as_stream(stream);
   const int kc = choose_conv_kernel(p, M);
-  if (kc == DP_CONV_BIG) {
-    a.tiles_n = p->Cout / kBigN;
-    a.n_tiles = (int)((M + kBigM - 1) / kBigM) * a.tiles_n;
-    return p->dtype == DP_F32 ? launch_conv_big<float>(a, s) : launch_conv_big<uint16_t>(a, s);
+  if (kc == DP_CONV_RING256) {
+    a.tiles_n = p->Cout / 256;
+    a.n_tiles = (int)((M + 255) / 256) * a.tiles_n;
+    return p->dtype == DP_F32 ? launch_conv_ring<float, 4, 8>(a, s) : launch_conv_ring<uint16_t, 4, 8>(a, s);
+  }
+  if (kc == DP_CONV_RING128) {
+    a.tiles_n = (p->Cout + 127) / 128;
+    a.n_tiles = (int)((M + 127) / 128) * a.tiles_n;
+    return p->dtype == DP_F32 ? launch_conv_ring<float, 2, 4>(a, s) : launch_conv_ring<uint16_t, 2, 4>(a, s);
   }
   const int tiles_m = (int)((M + kBM - 1) / kBM);
   if (kc == DP_CONV_K64) {

@@ -92,6 +92,7 @@ class Engine:
         p.Ho, p.Wo, p.Cout = Ho, Wo, layer.cout
         p.Cout_w, p.Kpad = layer.cout_w, layer.kpad
         p.stride = s
+        p.ntaps = layer.ntaps
         if residual is not None:
             p.rsN, p.rsH, p.rsW = residual.H * residual.W * residual.C, residual.W * residual.C, residual.C
             assert residual.C == layer.cout
@@ -106,7 +107,7 @@ class Engine:
             e0.record()
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
             e1.record()
-            cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_igemm_big_kernel")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
+            cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_ring_kernel<256x256>", "conv_ring_kernel<128x128>")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
             self.prof.append((cls, flops, e0, e1, layer.name))
         else:
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)

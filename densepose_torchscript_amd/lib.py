@@ -27,7 +27,7 @@ class ConvParams(C.Structure):
                 ("N", c_i32), ("H", c_i32), ("W", c_i32), ("Cin", c_i32),
                 ("Ho", c_i32), ("Wo", c_i32), ("Cout", c_i32),
                 ("Cout_w", c_i32), ("Kpad", c_i32),
-                ("stride", c_i32), ("pad_unused", c_i32),
+                ("stride", c_i32), ("ntaps", c_i32),
                 ("osN", c_i64), ("osH", c_i64), ("osW", c_i64),
                 ("rsN", c_i64), ("rsH", c_i64), ("rsW", c_i64),
                 ("rshift", c_i32), ("relu", c_i32), ("dtype", c_i32), ("out_f32", c_i32),

@@ -38,6 +38,15 @@ class PackedConv:
         self.kpad = round_up(k, 128 // es)
         full = np.zeros((self.cout_w, nt, cin_alloc), dtype=np.float32)
         full[:co, :, :ci] = wmat
+        pe = 64 // es  # elements of one 64-byte K plane
+        # K order. Multi-tap layers whose channel count is a whole number of planes are packed CHANNEL-BLOCK major,
+        # taps inner: consecutive K planes then read the same pixels shifted by one tap, so the 3 dx taps (and, through
+        # the neighbouring tiles that run at the same time on the same XCD, the 3 dy taps) of an activation hit in L2
+        # instead of being re-fetched from beyond it 9 times (tap-major order sweeps the whole input once per tap).
+        self.plane_major = nt > 1 and cin_alloc % pe == 0
+        if self.plane_major:
+            ncb = cin_alloc // pe
+            full = full.reshape(self.cout_w, nt, ncb, pe).transpose(0, 2, 1, 3)  # [co, cblock, tap, pe]
         flat = np.zeros((self.cout_w, self.kpad), dtype=np.float32)
         flat[:, :k] = full.reshape(self.cout_w, k)
         t = torch.from_numpy(flat)
@@ -48,14 +57,21 @@ class PackedConv:
         ktab = np.zeros((nchunk, 4), dtype=np.int32)
         for kc in range(nchunk):
             k0 = kc * ch
-            tap = k0 // cin_alloc
-            if tap < nt:
-                ktab[kc] = (taps[tap][0], taps[tap][1], k0 % cin_alloc, 1)
+            if k0 >= k:
+                continue
+            if self.plane_major:
+                plane, within = divmod(k0, pe)
+                cb, tap = divmod(plane, nt)
+                c0 = cb * pe + within
+            else:
+                tap, c0 = divmod(k0, cin_alloc)
+            ktab[kc] = (taps[tap][0], taps[tap][1], c0, 1 | (tap << 8))
         self.ktab = torch.from_numpy(ktab).to(device)
         b = np.zeros((self.cout_w,), dtype=np.float32)
         if bias is not None:
             b[:co] = bias
         self.bias = torch.from_numpy(b).to(device)
+        self.ntaps = nt
         self.stride = stride
         self.hi_off = hi_off
         self.wi_off = wi_off

@@ -65,14 +65,14 @@ int dp_preprocess_u8(const dp_preprocess_params* p, dp_stream_t stream);
 typedef struct {
   const void* in;        /* [N][H][W][Cin] dtype, Cin % 8 == 0 */
   const void* weight;    /* [Cout_w][Kpad] dtype, K-contiguous; Cout_w % 128 == 0, zero padded */
-  const int32_t* ktab;   /* [Kpad / chunk][4] */
+  const int32_t* ktab;   /* [Kpad / chunk][4] = {dy, dx, c0, valid | tap << 8} */
   const float* bias;     /* [Cout_w] fp32 (BN shift or conv bias), zero padded */
   const void* residual;  /* optional, dtype; element (n,ho,wo,c) at n*rsN + (ho>>rshift)*rsH + (wo>>rshift)*rsW + c */
   void* out;             /* element (n,ho,wo,c) at n*osN + ho*osH + wo*osW + c */
   int32_t N, H, W, Cin;
   int32_t Ho, Wo, Cout;  /* Cout = channels stored (multiple of 8, <= Cout_w) */
   int32_t Cout_w, Kpad;
-  int32_t stride, pad_unused;
+  int32_t stride, ntaps;  /* ntaps = number of (dy,dx) taps in ktab; ktab[k].w = valid | tap_index << 8 */
   int64_t osN, osH, osW;
   int64_t rsN, rsH, rsW;
   int32_t rshift;
@@ -82,7 +82,7 @@ typedef struct {
   int32_t hi_off, wi_off; /* input pixel of output (ho,wo), tap (dy,dx): (ho*stride + hi_off + dy, wo*stride + wi_off + dx) */
 } dp_conv_params;
 int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
-/* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = 128x64 tile, 1 = 128x128 tile, 2 = 256x256 LDS-ring tile
+/* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile, 3 = 128x128 LDS-ring tile
  * (profiling / roofline bookkeeping only) */
 int dp_conv2d_kernel_class(const dp_conv_params* p);
 

@@ -51,13 +51,17 @@ BIG_CASES = [
     (1, 256, 40, 56, 256, 3, 1, 1, 1, True, False),
     (2, 1024, 9, 11, 512, 1, 2, 0, 1, False, False),
     (1, 32, 30, 30, 256, 3, 1, 2, 2, False, False),
+    (1, 64, 17, 23, 40, 3, 1, 1, 1, True, False),     # Cout not a multiple of 128 (128x128 ring only; 256 falls back)
+    (2, 32, 5, 7, 256, 1, 1, 0, 1, False, False),     # a single K plane
+    (1, 96, 12, 12, 128, 1, 1, 0, 1, True, True),     # three K planes
 ]
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("force", ["1", "2"])   # 1: 256x256 ring kernel, 2: 128x128 ring kernel
 @pytest.mark.parametrize("case", BIG_CASES)
-def test_conv2d_large_tile_kernel(eng, dt, case, monkeypatch):
-    monkeypatch.setenv("DP_CONV_BIG", "1")
+def test_conv2d_ring_kernels(eng, dt, case, force, monkeypatch):
+    monkeypatch.setenv("DP_CONV_BIG", force)
     test_conv2d_matches_torch(eng, dt, case)
 
 
