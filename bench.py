@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--dets", type=int, default=8, help="detections per image (R), pinned via TEST.DETECTIONS_PER_IMAGE")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--streams", type=int, default=2, help="sub-batches of a step run concurrently on this many HIP streams")
+    ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     args = ap.parse_args()
@@ -92,7 +94,7 @@ def main():
         for k in state:
             if k.endswith("running_var"):
                 state[k] += 1.0
-    pred = DensePosePredictor(cfg, state, dtype=args.dtype, device=device, resize="device")
+    pred = DensePosePredictor(cfg, state, dtype=args.dtype, device=device, resize="device", num_streams=args.streams, use_graphs=not args.no_graphs)
     if world > 1:
         parallel.broadcast_tensors(pred.engine.model.parameter_tensors(), src=0)
     eng = pred.engine

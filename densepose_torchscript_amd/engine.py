@@ -54,6 +54,9 @@ class Engine:
         self.inter = {}
         self.flops_last = 0
         self.prof = None  # list of (kernel class, algorithmic flops, start event, end event) when profiling
+        self.use_graphs = False
+        self._graphs = {}
+        self._pinned = {}
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -369,17 +372,13 @@ class Engine:
         return coarse, fine, u, v, offs
 
     # ------------------------------------------------------------------ whole path for a batch of equal-size frames
-    @torch.no_grad()
-    def forward_batch(self, images_u8, orig_hw, given_boxes=None):
-        """images_u8: uint8 [n,3,h,w] on the device (already resized, defaults.py:89). orig_hw: list of (H, W).
-        Returns a list of n dicts with the reference's 8 keys (postprocessing.py:52-61)."""
-        cfg = self.cfg
+    # ------------------------------------------------------------------ whole path for a batch of equal-size frames
+    def _phase_a(self, images_u8, given_boxes=None):
+        """preprocess -> backbone -> RPN -> box head -> detection select (everything whose launch sizes are static)."""
         assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[1] == 3
         images_u8 = images_u8.contiguous()
         n, _, h, w = images_u8.shape
         Hp, Wp = round_up(h, 32), round_up(w, 32)
-        self.flops_last = 0
-        self.inter = {}
         x = self.preprocess(images_u8, Hp, Wp)
         feats = self.backbone(x)
         if self.keep_intermediates:
@@ -391,18 +390,65 @@ class Engine:
             det_boxes, det_scores, det_counts = self.box_branch(feats, props, prop_counts)
         else:
             det_boxes, det_scores, det_counts = given_boxes
-        counts_host = det_counts.cpu().numpy().astype(np.int64)  # the one host sync of the path: R sizes the head launches
-        coarse, fine, u, v, offs = self.densepose_branch(feats, det_boxes, det_counts, counts_host)
+        return dict(n=n, h=h, w=w, feats=feats, det_boxes=det_boxes, det_scores=det_scores, det_counts=det_counts)
+
+    def _pinned_counts(self, key, n):
+        buf = self._pinned.get(key)
+        if buf is None or buf.numel() < n:
+            buf = torch.empty((max(n, 8),), dtype=torch.int32, pin_memory=True)  # cudaHostAlloc is slow: allocate once
+            self._pinned[key] = buf
+        return buf[:n]
+
+    def _phase_a_run(self, images_u8, slot, given_boxes=None):
+        """Phase A + asynchronous read-back of the detection counts. With ``use_graphs`` the launch sequence of a given
+        (sub-batch shape, stream slot) is captured once into a HIP graph and replayed: the ~200 kernel launches of the
+        static part cost one graph launch on the host instead of ~200 x (ctypes call + hipLaunchKernel)."""
+        n = images_u8.shape[0]
+        graphable = self.use_graphs and given_boxes is None and not self.keep_intermediates and self.prof is None
+        if not graphable:
+            st = self._phase_a(images_u8, given_boxes)
+            pinned = self._pinned_counts(("eager", slot), n)
+            pinned.copy_(st["det_counts"], non_blocking=True)
+        else:
+            key = (tuple(images_u8.shape), slot)
+            entry = self._graphs.get(key)
+            if entry is None:
+                static_in = images_u8.clone()
+                self._phase_a(static_in)            # eager warm-up: one-time attribute / table initialisation outside capture
+                torch.cuda.current_stream(self.device).synchronize()
+                pinned = self._pinned_counts(key, n)
+                graph = torch.cuda.CUDAGraph()
+                flops0 = self.flops_last
+                with torch.cuda.graph(graph):
+                    st = self._phase_a(static_in)
+                    pinned.copy_(st["det_counts"], non_blocking=True)
+                entry = (graph, static_in, st, pinned, self.flops_last - flops0)
+                self._graphs[key] = entry
+                self.flops_last = flops0
+            graph, static_in, st, pinned, flops = entry
+            static_in.copy_(images_u8, non_blocking=True)
+            graph.replay()
+            self.flops_last += flops
+            st = dict(st)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["counts_pinned"], st["counts_event"] = pinned, ev
+        return st
+
+    def _phase_b(self, st, orig_hw):
+        """DensePose branch (sized by the detection counts R - the one host read-back of the path) + postprocess."""
+        n, h, w = st["n"], st["h"], st["w"]
+        det_boxes, det_scores, det_counts = st["det_boxes"], st["det_scores"], st["det_counts"]
+        st["counts_event"].synchronize()
+        counts_host = st["counts_pinned"].numpy().astype(np.int64)
+        coarse, fine, u, v, offs = self.densepose_branch(st["feats"], det_boxes, det_counts, counts_host)
         # detector_postprocess (postprocessing.py:43-54); image_size there is [W_pad, H_pad] (Q1) minus the padding
         D = det_boxes.shape[1]
-        scale_xy = np.zeros((n, 2), dtype=np.float32)
-        out_hw = np.zeros((n, 2), dtype=np.float32)
+        meta = np.zeros((n, 4), dtype=np.float32)
         for i, (H0, W0) in enumerate(orig_hw):
-            scale_xy[i, 0] = np.float32(W0) / np.float32(w)
-            scale_xy[i, 1] = np.float32(H0) / np.float32(h)
-            out_hw[i] = (H0, W0)
-        scale_d = torch.from_numpy(scale_xy).to(self.device)
-        hw_d = torch.from_numpy(out_hw).to(self.device)
+            meta[i] = (np.float32(W0) / np.float32(w), np.float32(H0) / np.float32(h), H0, W0)
+        meta_d = torch.from_numpy(meta).to(self.device, non_blocking=True)
+        scale_d, hw_d = meta_d[:, :2].contiguous(), meta_d[:, 2:].contiguous()
         fin_boxes = self._empty((n, D, 4), torch.float32)
         keep = self._empty((n, D), torch.int32)
         p = L.PostprocessParams()
@@ -410,11 +456,10 @@ class Engine:
         p.scale_xy, p.out_hw, p.out_boxes, p.keep = scale_d.data_ptr(), hw_d.data_ptr(), fin_boxes.data_ptr(), keep.data_ptr()
         L.check(self.lib.dp_postprocess_boxes(C.byref(p), self._stream()), "dp_postprocess_boxes")
         results = []
-        keep_h = None
         for i in range(n):
             r = int(counts_host[i])
             o = int(offs[i])
-            res = {
+            results.append({
                 "image_size": torch.tensor([orig_hw[i][0], orig_hw[i][1]], dtype=torch.int64),
                 "pred_boxes": fin_boxes[i, :r],
                 "scores": det_scores[i, :r],
@@ -423,23 +468,62 @@ class Engine:
                 "pred_densepose_fine_segm": fine[o:o + r],
                 "pred_densepose_u": u[o:o + r],
                 "pred_densepose_v": v[o:o + r],
-            }
-            results.append(res)
-        # nonempty filter of postprocessing.py:51 (w >= 0 & h >= 0): always true for decoded boxes; verify lazily
-        self._pending_keep = (keep, counts_host)
+            })
+        return results, (keep, counts_host)
+
+    @torch.no_grad()
+    def forward_batch(self, images_u8, orig_hw, given_boxes=None, num_streams=1):
+        """images_u8: uint8 [n,3,h,w] on the device (already resized, defaults.py:89). orig_hw: list of (H, W).
+        Returns a list of n dicts with the reference's 8 keys (postprocessing.py:52-61).
+
+        num_streams > 1 splits the batch into that many sub-batches, each running the whole path on its own HIP stream:
+        frames are independent, so the sub-batches' kernels fill each other's partial waves / tails and the
+        detection-count read-back of one overlaps the other's kernels. Results are identical to num_streams=1."""
+        n = images_u8.shape[0]
+        self.flops_last = 0
+        self.inter = {}
+        g = max(1, min(int(num_streams), n)) if given_boxes is None else 1
+        if g == 1:
+            st = self._phase_a_run(images_u8, 0, given_boxes)
+            results, keep = self._phase_b(st, orig_hw)
+            self._pending_keep = [(keep, 0)]
+            return results
+        if not hasattr(self, "_streams") or len(self._streams) < g:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(g)]
+        main = torch.cuda.current_stream(self.device)
+        bounds = [(i * n) // g for i in range(g + 1)]
+        states = []
+        for k in range(g):
+            s = self._streams[k]
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                states.append(self._phase_a_run(images_u8[bounds[k]:bounds[k + 1]], k + 1))
+        results, self._pending_keep = [], []
+        for k in range(g):
+            with torch.cuda.stream(self._streams[k]):
+                res, keep = self._phase_b(states[k], orig_hw[bounds[k]:bounds[k + 1]])
+            for r in res:
+                for t in r.values():
+                    if t.is_cuda:
+                        t.record_stream(main)
+            self._pending_keep.append((keep, bounds[k]))
+            results.extend(res)
+        for k in range(g):
+            main.wait_stream(self._streams[k])
         return results
 
     def apply_keep_filter(self, results):
         """Drops detections whose rescaled box has negative extent (cannot happen for finite decoded boxes; kept for
         bug-compatibility with postprocessing.py:51). Costs one extra sync, so callers may skip it."""
-        keep, counts_host = self._pending_keep
-        kh = keep.cpu().numpy()
-        for i, res in enumerate(results):
-            r = int(counts_host[i])
-            k = kh[i, :r].astype(bool)
-            if not k.all():
-                idx = torch.from_numpy(np.nonzero(k)[0]).to(self.device)
-                for key in list(res):
-                    if key != "image_size":
-                        res[key] = res[key][idx]
+        for (keep, counts_host), first in self._pending_keep:
+            kh = keep.cpu().numpy()
+            for i in range(len(counts_host)):
+                res = results[first + i]
+                r = int(counts_host[i])
+                k = kh[i, :r].astype(bool)
+                if not k.all():
+                    idx = torch.from_numpy(np.nonzero(k)[0]).to(self.device)
+                    for key in list(res):
+                        if key != "image_size":
+                            res[key] = res[key][idx]
         return results

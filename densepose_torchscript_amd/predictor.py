@@ -21,7 +21,7 @@ from .weights import check_state, load_checkpoint
 
 
 class DensePosePredictor:
-    def __init__(self, cfg, weights, dtype="bf16", device="cuda:0", resize="host"):
+    def __init__(self, cfg, weights, dtype="bf16", device="cuda:0", resize="host", num_streams=2, use_graphs=False):
         """cfg: ModelConfig | variant name | yaml path. weights: path to .pkl/.pth or a canonical state dict."""
         if not isinstance(cfg, ModelConfig):
             cfg = get_config(cfg)
@@ -35,6 +35,8 @@ class DensePosePredictor:
         self.engine = Engine(cfg, state, dtype=dtype, device=device)
         self.device = self.engine.device
         self.resize_mode = resize  # "host": torch CPU uint8 kernel exactly as the reference (Q4) ; "device": HIP kernel
+        self.num_streams = num_streams  # sub-batches of a batch run concurrently on this many HIP streams
+        self.engine.use_graphs = use_graphs  # replay the static part of the path (backbone .. detection select) as a HIP graph
 
     # -- defaults.py:76-89 ---------------------------------------------------------------------------------
     def _to_chw(self, original_image, bgr):
@@ -78,7 +80,7 @@ class DensePosePredictor:
         for (h, w), idxs in groups.items():
             batch = torch.stack([resized[i] for i in idxs])
             orig = [(int(chws[i].shape[1]), int(chws[i].shape[2])) for i in idxs]
-            res = self.engine.forward_batch(batch, orig)
+            res = self.engine.forward_batch(batch, orig, num_streams=self.num_streams if len(idxs) >= 4 else 1)
             res = self.engine.apply_keep_filter(res)
             for i, r in zip(idxs, res):
                 out[i] = r
