@@ -22,6 +22,7 @@
 //     run on the same XCD and share its L2.
 #include "dp_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -324,6 +325,14 @@ __device__ __forceinline__ void wait_vmcnt() {
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 template <typename T, int WC, int TP>
 __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArgs p) {
   constexpr int ES = sizeof(T);
@@ -462,7 +471,52 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
   __builtin_amdgcn_s_barrier();
   DP_RING_READ(0, fpA, fcA);
 
-  for (int s = 0; s < ns; s += 2) {
+  // Steady-state step (planes S+1 .. S+3 all exist): branch-free, with the four LDS-DMA pieces of plane S+3 and the TC+TP
+  // fragment reads of plane S+1 issued one at a time between groups of MFMAs of plane S (order pinned by sched_barrier
+  // fences). Both waves of a SIMD start their MFMAs right after the barrier and each wave's memory-instruction issue
+  // slots fall under its partner's MFMAs instead of both waves idling the matrix pipe together.
+  constexpr int N_MEM = 4 + TC + TP;            // memory instructions per step
+  constexpr int N_PAIR = TC * TP;               // fragment pairs (MFMA groups) per step
+  auto steady = [&](int S, u32x4 (&fp_cur)[TP], u32x4 (&fc_cur)[TC], u32x4 (&fp_nxt)[TP], u32x4 (&fc_nxt)[TC]) __attribute__((always_inline)) {
+    wait_vmcnt<4>();
+    __builtin_amdgcn_s_barrier();
+    const i32x4 e = e_nx;
+    const int tap_boff = ((e[0] * p.W + e[1]) * p.Cin + e[2]) * ES;
+    const unsigned tapbit = (e[3] & 1) ? (1u << (e[3] >> 8)) : 0u;
+    unsigned char* dst = lds_st + ((S + 3) & (kRing - 1)) * SLOT;
+    const int rslot = ((S + 1) & (kRing - 1)) * SLOT;
+    e_nx = ktab_c[min(S + 4, ns - 1) * 4];
+    static_for<0, N_PAIR>([&](auto pi) {
+      constexpr int pr = decltype(pi)::value;
+      Mma<T>::run(fc_cur[pr / TP], fp_cur[pr % TP], acc[pr / TP][pr % TP]);
+      // memory instructions spread evenly over the MFMA groups
+      constexpr int m_lo = pr * N_MEM / N_PAIR, m_hi = (pr + 1) * N_MEM / N_PAIR;
+      if constexpr (m_hi > m_lo) {
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<m_lo, m_hi>([&](auto mi) {
+          constexpr int m = decltype(mi)::value;
+          if constexpr (m < 2) {
+            const int off = (a_okm[m] & tapbit) ? (a_boff[m] + tap_boff) : (int)0x80000000;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(dst + m * 1024), 16, off, 0, 0, 0);
+          } else if constexpr (m < 4) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DP_LDS_PTR(dst + A_PLANE + (m - 2) * 1024), 16,
+                                                     w_boff + (16 * (m - 2) * p.Kpad + (S + 3) * PE) * ES, 0, 0, 0);
+          } else if constexpr (m < 4 + TC) {
+            fc_nxt[m - 4] = *reinterpret_cast<const u32x4*>(rd_b + rslot + (m - 4) * 16 * 64);
+          } else {
+            fp_nxt[m - 4 - TC] = *reinterpret_cast<const u32x4*>(rd_a + rslot + (m - 4 - TC) * 16 * 64);
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+  };
+  int s = 0;
+  for (; s + 5 <= ns; s += 2) {   // both steps of the pair have planes s+1 .. s+4 ahead of them
+    steady(s, fpA, fcA, fpB, fcB);
+    steady(s + 1, fpB, fcB, fpA, fcA);
+  }
+  for (; s < ns; s += 2) {        // tail: the generic step (conditional staging / counted waits)
     DP_RING_STEP(s, fpA, fcA, fpB, fcB);
     if (s + 1 < ns) DP_RING_STEP(s + 1, fpB, fcB, fpA, fcA);
   }
