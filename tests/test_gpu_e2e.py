@@ -160,3 +160,42 @@ def test_streams_and_graphs_do_not_change_results():
         for a, b in zip(base, out):
             for k in a:
                 assert torch.equal(a[k].cpu(), b[k].cpu()), (streams, graphs, k)
+
+
+def test_zero_and_many_detections():
+    """R = 0 is legal (empty tensors with the right shapes/dtypes); a low threshold gives the DETECTIONS_PER_IMAGE cap."""
+    from densepose_torchscript_amd import TINY_OPTS, get_config, make_synthetic_state
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    from oracle.ref_cpu import OracleModel
+    img = torch.from_numpy(np.random.default_rng(3).integers(0, 256, (100, 150, 3), dtype=np.uint8))
+    for opts, expect in ((["MODEL.ROI_HEADS.SCORE_THRESH_TEST", 0.9999], "zero"),
+                         (["MODEL.ROI_HEADS.SCORE_THRESH_TEST", 0.0, "TEST.DETECTIONS_PER_IMAGE", 20], "many")):
+        cfg = get_config("densepose_rcnn_R_50_FPN_s1x", TINY_OPTS + ["MODEL.ROI_DENSEPOSE_HEAD.POOLER_RESOLUTION", 7] + opts)
+        state = make_synthetic_state(cfg, 5)
+        out = DensePosePredictor(cfg, state, dtype="fp32")(img)
+        ref = OracleModel(cfg, state)(img)
+        torch.cuda.synchronize()
+        R = ref["scores"].shape[0]
+        assert (R == 0) if expect == "zero" else (R == 20)
+        for k in ref:
+            assert tuple(out[k].shape) == tuple(ref[k].shape) and out[k].dtype == ref[k].dtype, (k, out[k].shape, ref[k].shape)
+        if R:
+            assert (out["pred_densepose_u"].cpu() - ref["pred_densepose_u"]).abs().max().item() <= IUV_ATOL
+
+
+def test_video_frame_geometry_and_chw_input():
+    """1080x1920 frame (-> 749x1333, padded 768x1344) given as CHW; same result as HWC."""
+    from densepose_torchscript_amd import TINY_OPTS, get_config, make_synthetic_state
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    cfg = get_config("densepose_rcnn_R_50_FPN_s1x", TINY_OPTS + ["MODEL.ROI_DENSEPOSE_HEAD.POOLER_RESOLUTION", 7,
+                                                                "INPUT.MIN_SIZE_TEST", 800, "INPUT.MAX_SIZE_TEST", 1333])
+    state = make_synthetic_state(cfg, 6)
+    pred = DensePosePredictor(cfg, state, dtype="fp32")
+    img = torch.from_numpy(np.random.default_rng(4).integers(0, 256, (1080, 1920, 3), dtype=np.uint8))
+    a = pred(img)
+    b = pred(img.permute(2, 0, 1).contiguous())
+    assert a["image_size"].tolist() == [1080, 1920]
+    for k in a:
+        assert torch.equal(a[k].cpu(), b[k].cpu()), k
+    with pytest.raises(AssertionError):
+        pred(torch.zeros((10, 10, 4), dtype=torch.uint8))
