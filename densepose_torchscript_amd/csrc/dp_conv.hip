@@ -91,6 +91,7 @@ template <typename T, int COLS, int NTHREADS>
 __device__ __forceinline__ void drain_rows(const ConvArgs& p, const float* lds, int rows, int m_base, int n_base, int tid) {
   constexpr int LPR = COLS / 8;              // lanes per pixel row
   constexpr int RPP = NTHREADS / LPR;        // rows per pass
+  static_assert(RPP % 8 == 0, "the row swizzle (r & 7) must be the same for every row a thread drains");
   const int q = tid % LPR;                   // 8-channel group inside the tile
   const int r0 = tid / LPR;
   const int co = n_base + q * 8;
@@ -98,25 +99,17 @@ __device__ __forceinline__ void drain_rows(const ConvArgs& p, const float* lds, 
   const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + co);
   const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + co + 4);
   const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
-  for (int r = r0; r < rows; r += RPP) {
-    const int m = m_base + r;
-    if (m >= p.M) break;
-    const int c0 = ((2 * q) ^ (r & 7)) * 4, c1 = ((2 * q + 1) ^ (r & 7)) * 4;
-    f32x4 v0 = *reinterpret_cast<const f32x4*>(lds + r * COLS + c0);
-    f32x4 v1 = *reinterpret_cast<const f32x4*>(lds + r * COLS + c1);
+  const int nrows = min(rows, p.M - m_base);
+  const int sw = r0 & 7;
+  const float* l0 = lds + r0 * COLS + ((2 * q) ^ sw) * 4;
+  const float* l1 = lds + r0 * COLS + ((2 * q + 1) ^ sw) * 4;
+  const bool f32_out = p.out_f32 || sizeof(T) == 4;
+
+  auto finish = [&](f32x4 v0, f32x4 v1, const T* rp, void* op) __attribute__((always_inline)) {
     v0 += b0;
     v1 += b1;
-    // plain NHWC tensors: element offset = m * pixel stride, no (n, ho, wo) decomposition (two integer divisions)
-    int n = 0, ho = 0, wo = 0;
-    if (!p.out_linear || (res && !p.res_linear)) {
-      n = m / p.HoWo;
-      const int rem = m - n * p.HoWo;
-      ho = rem / p.Wo;
-      wo = rem - ho * p.Wo;
-    }
-    if (res) {
-      const long long rb = (p.res_linear ? (long long)m * p.rsW : n * p.rsN + (ho >> p.rshift) * p.rsH + (wo >> p.rshift) * p.rsW) + co;
-      const float4 ra = load4(res + rb), rc = load4(res + rb + 4);
+    if (rp) {
+      const float4 ra = load4(rp), rc = load4(rp + 4);
       v0[0] += ra.x; v0[1] += ra.y; v0[2] += ra.z; v0[3] += ra.w;
       v1[0] += rc.x; v1[1] += rc.y; v1[2] += rc.z; v1[3] += rc.w;
     }
@@ -124,17 +117,45 @@ __device__ __forceinline__ void drain_rows(const ConvArgs& p, const float* lds, 
 #pragma unroll
       for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
     }
-    const long long ob = (p.out_linear ? (long long)m * p.osW : n * p.osN + ho * p.osH + wo * p.osW) + co;
-    if (p.out_f32 || sizeof(T) == 4) {
-      float* o = reinterpret_cast<float*>(p.out) + ob;
+    if (f32_out) {
+      float* o = reinterpret_cast<float*>(op);
       *reinterpret_cast<f32x4*>(o) = v0;
       *reinterpret_cast<f32x4*>(o + 4) = v1;
     } else {
       u32x4 pk;
       pk[0] = pack_bf16x2(v0[0], v0[1]); pk[1] = pack_bf16x2(v0[2], v0[3]);
       pk[2] = pack_bf16x2(v1[0], v1[1]); pk[3] = pack_bf16x2(v1[2], v1[3]);
-      *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.out) + ob) = pk;
+      *reinterpret_cast<u32x4*>(op) = pk;
     }
+  };
+
+  if (p.out_linear && (!res || p.res_linear)) {
+    // plain NHWC tensors: element offset = m * pixel stride -> pointers advance by a constant per row, no integer
+    // division / 64-bit multiply per row (the epilogue was VALU-bound on exactly that)
+    const long long ostep = (long long)RPP * p.osW, rstep = (long long)RPP * p.rsW;
+    const long long o0 = (long long)(m_base + r0) * p.osW + co;
+    unsigned char* op = reinterpret_cast<unsigned char*>(p.out) + o0 * (f32_out ? 4 : (long long)sizeof(T));
+    const long long obytes = ostep * (f32_out ? 4 : (long long)sizeof(T));
+    const T* rp = res ? res + (long long)(m_base + r0) * p.rsW + co : nullptr;
+    for (int r = r0; r < nrows; r += RPP) {
+      finish(*reinterpret_cast<const f32x4*>(l0), *reinterpret_cast<const f32x4*>(l1), rp, op);
+      l0 += RPP * COLS;
+      l1 += RPP * COLS;
+      op += obytes;
+      if (rp) rp += rstep;
+    }
+    return;
+  }
+  for (int r = r0; r < nrows; r += RPP, l0 += RPP * COLS, l1 += RPP * COLS) {
+    const int m = m_base + r;
+    const int n = m / p.HoWo;
+    const int rem = m - n * p.HoWo;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    const T* rp = res ? res + (n * p.rsN + (ho >> p.rshift) * p.rsH + (wo >> p.rshift) * p.rsW + co) : nullptr;
+    const long long ob = n * p.osN + ho * p.osH + wo * p.osW + co;
+    void* op = f32_out ? static_cast<void*>(reinterpret_cast<float*>(p.out) + ob) : static_cast<void*>(reinterpret_cast<T*>(p.out) + ob);
+    finish(*reinterpret_cast<const f32x4*>(l0), *reinterpret_cast<const f32x4*>(l1), rp, op);
   }
 }
 
