@@ -129,11 +129,21 @@ def main():
     dets = [int(o["scores"].shape[0]) for o in out]
     flops_step = eng.flops_last
 
-    # ---- roofline of the dominant kernel, HIP events on the launch stream, same K steps of the same workload ----
+    # ---- roofline of the dominant kernel: K further steps of the same workload, every conv launch bracketed by HIP events
+    # on the stream it is launched on. This pass runs the batch on ONE stream without graph replay, so each kernel has the
+    # chip to itself and the event delta is its own duration (in the timed region two sub-batches overlap on two streams,
+    # which inflates per-launch durations by the time spent sharing the CUs). profiles/ holds the rocprofv3 summary of the
+    # same serialized configuration (`--streams 1 --no-graphs`), whose per-kernel averages must agree with these.
+    pred.num_streams, eng.use_graphs = 1, False
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
     eng.prof = []
+    t_ser = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    t_ser = (time.perf_counter() - t_ser) / args.steps
     agg = {}
     for cls, flops, e0, e1, name in eng.prof:
         a = agg.setdefault(cls, [0, 0.0, 0])
@@ -141,14 +151,22 @@ def main():
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
     eng.prof = None
+    pred.num_streams, eng.use_graphs = args.streams, not args.no_graphs
     dom = max(agg, key=lambda c: agg[c][1])
     dflops, dsec, dcalls = agg[dom]
     peak = PEAK_BF16_DENSE if args.dtype == "bf16" else PEAK_F32_MATRIX
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
+    if os.path.exists(tpath) and args.dtype == "bf16" and args.config == "densepose_rcnn_R_50_FPN_s1x" and args.batch == 8:
+        k = json.load(open(tpath))["kernels"].get(dom + "[bf16]")
+        if k:
+            traffic = {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "source": "profiles/r1_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"}
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round(dflops / dsec / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
-                "frac": round(dflops / dsec / peak, 4), "traffic": None,
+                "frac": round(dflops / dsec / peak, 4), "traffic": traffic,
                 "launches_per_step": dcalls // args.steps, "avg_launch_us": round(1e6 * dsec / dcalls, 2),
                 "alg_gflop_per_launch": round(dflops / dcalls / 1e9, 3),
-                "share_of_step_time": round(dsec / args.steps / (elapsed / args.steps), 3),
+                "share_of_serialized_step": round(dsec / args.steps / t_ser, 3),
+                "measured": "K event-instrumented steps on one stream (kernels alone on the chip), %.2f ms/step serialized" % (1e3 * t_ser),
                 "all_conv_classes": {c: {"tflops": round(v[0] / v[1] / 1e12, 2), "calls_per_step": v[2] // args.steps,
                                          "ms_per_step": round(1e3 * v[1] / args.steps, 3)} for c, v in agg.items()}}
 
@@ -156,7 +174,8 @@ def main():
     if rank == 0:
         images = args.batch * world * args.steps
         result = {
-            "metric": "images/sec at 1/2/4/8 MI355X, R_50_FPN_s1x 800x1333; p50 ms/img",
+            "metric": "images/sec at 1/2/4/8 MI355X, R_50_FPN_s1x 800x1333; p50 ms/img" if args.config == "densepose_rcnn_R_50_FPN_s1x"
+                      else "images/sec, %s 800x1333" % args.config,
             "value": round(images / elapsed, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),

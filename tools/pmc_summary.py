@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc counter_collection CSVs into per-kernel HBM traffic per launch.
+
+    python tools/pmc_summary.py FETCH_CSV WRITE_CSV > profiles/rN_hbm_traffic.json
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B... (rocprofv3: kilobytes); per MI355X_MICROARCH.md §HBM,
+on gfx950 FETCH_SIZE reads exactly HALF of the bytes of a wide coalesced streaming read, so it is doubled here;
+WRITE_SIZE is exact for 16-byte-per-lane stores. The two counters need separate passes (TCC slots)."""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def short(name):
+    m = re.search(r"(conv_ring_kernel|conv_igemm_kernel)<([^>]*)>", name)
+    if m:
+        args = [a.strip() for a in m.group(2).split(",")]
+        dt = "bf16" if args[0] == "unsigned short" else "f32"
+        if m.group(1) == "conv_ring_kernel":
+            return "conv_ring_kernel<%s>[%s]" % ("256x256" if args[1] == "4" else "128x128", dt)
+        return "conv_igemm_kernel<%s>[%s]" % (args[1], dt)
+    m = re.search(r"::(\w+)(<|\()", name)
+    return m.group(1) if m else name[:60]
+
+
+def load(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        f = fetch.get(k, [])
+        w = write.get(k, [])
+        fb = 2.0 * 1024.0 * sum(f) / max(len(f), 1)   # gfx950 correction x2
+        wb = 1024.0 * sum(w) / max(len(w), 1)
+        out[k] = {"launches_profiled": max(len(f), len(w)), "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
+                  "hbm_bytes_per_launch": round(fb + wb)}
+    json.dump({"note": "FETCH_SIZE x2 (gfx950 under-reports wide streaming reads by 1/2), WRITE_SIZE as is; units: bytes per launch, "
+                       "averaged over the launches of each kernel in `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graphs --streams 1`",
+               "kernels": out}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
