@@ -199,3 +199,22 @@ def test_video_frame_geometry_and_chw_input():
         assert torch.equal(a[k].cpu(), b[k].cpu()), k
     with pytest.raises(AssertionError):
         pred(torch.zeros((10, 10, 4), dtype=torch.uint8))
+
+
+def test_gpu_iuv_extract_matches_reference_visualizer_golden():
+    """densepose_torchscript_amd.visualizer.extract_iuv (dp_iuv_extract) vs the labels/uv the reference's
+    DensePoseResultExtractor produced (visualizer.py:46-56), on the engine's own fp32 outputs."""
+    from densepose_torchscript_amd.visualizer import extract_iuv, iuv_image
+    meta, z, cfg, pred, out = _run("tiny_r50_s1x_a", "fp32")
+    dev_out = {k: (v.cuda() if k != "image_size" else v) for k, v in out.items()}
+    results, xywh = extract_iuv(dev_out)
+    assert len(results) == z["out/scores"].shape[0]
+    for i, r in enumerate(results):
+        ref_l, ref_uv = z["vis/labels_%d" % i], z["vis/uv_%d" % i]
+        lab = r["labels"].cpu().numpy()
+        assert lab.shape == ref_l.shape
+        assert (lab != ref_l).mean() <= 0.002
+        same = lab == ref_l
+        np.testing.assert_allclose(r["uv"].cpu().numpy()[:, same], ref_uv[:, same], atol=IUV_ATOL)
+    img = iuv_image(results, xywh, int(out["image_size"][0]), int(out["image_size"][1]))
+    assert img.shape == (3, int(out["image_size"][0]), int(out["image_size"][1])) and img.dtype == np.uint8
