@@ -70,5 +70,25 @@ __device__ __forceinline__ void store4(uint16_t* p, float4 v) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
 }
 
+// 8 consecutive channels: ONE 16-byte access for bf16, two for f32
+__device__ __forceinline__ void load8(const float* p, float (&o)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void load8(const uint16_t* p, float (&o)[8]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  o[0] = bf16_bits_to_f32(u.x & 0xffffu); o[1] = bf16_bits_to_f32(u.x >> 16);
+  o[2] = bf16_bits_to_f32(u.y & 0xffffu); o[3] = bf16_bits_to_f32(u.y >> 16);
+  o[4] = bf16_bits_to_f32(u.z & 0xffffu); o[5] = bf16_bits_to_f32(u.z >> 16);
+  o[6] = bf16_bits_to_f32(u.w & 0xffffu); o[7] = bf16_bits_to_f32(u.w >> 16);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(uint16_t* p, const float (&v)[8]) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+
 static inline hipStream_t as_stream(dp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

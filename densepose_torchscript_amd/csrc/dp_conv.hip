@@ -601,13 +601,164 @@ int launch_conv_k(const ConvArgs& a, hipStream_t stream) {
   return a.n_ktiles <= 8 ? launch_conv<T, BN, 1>(a, stream) : launch_conv<T, BN, 2>(a, stream);
 }
 
+// =====================================================================================================
+// 256 pixels x 128 couts, 8 waves (64 x 64 each, 64 accumulator VGPRs), 3-slot ring of 24 KiB planes, <= 128 VGPRs:
+// TWO workgroups (16 waves, 4 per SIMD) are resident per CU. One workgroup's prologue / epilogue (whose burst of
+// output stores is HBM-write bound when every CU reaches it at the same time) overlaps the other's MFMA loop, and four
+// waves per SIMD cover each other's LDS-DMA / ds_read latencies without a second fragment register set.
+// =====================================================================================================
+constexpr int kR2Slots = 3;
+
+template <typename T>
+__global__ __launch_bounds__(512, 4) void conv_ring2_kernel(const ConvArgs p) {
+  constexpr int ES = sizeof(T);
+  constexpr int CH = 16 / ES;
+  constexpr int PE = 64 / ES;
+  constexpr int TC = 4, TP = 4;
+  constexpr int BM = 256, BN = 128;
+  constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, SLOT = A_PLANE + B_PLANE;   // 24 KiB
+  constexpr int NT = 512;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  int tile;
+  {
+    const int nwg = p.n_tiles, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  }
+  const int mt = tile / p.tiles_n;
+  const int nt = tile - mt * p.tiles_n;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 1;    // cout half (64)
+  const int wp = wave >> 1;   // pixel quarter (64)
+
+  const int srow = lane >> 2;
+  const int scc = (lane & 3) ^ swz(srow);
+  const __attribute__((address_space(4))) i32x4* ktab_c = (const __attribute__((address_space(4))) i32x4*)p.ktab;
+
+  // staging: A plane = 16 pieces of 16 rows (2 per wave: rows 32*wave + 16*i + srow), B plane = 8 pieces (1 per wave)
+  int a_boff[2];
+  unsigned a_okm[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wave * 32 + i * 16 + srow;
+    a_okm[i] = 0u;
+    a_boff[i] = 0;
+    if (m < p.M) {
+      const int n = m / p.HoWo;
+      const int rem = m - n * p.HoWo;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      const int hi0 = ho * p.stride + p.hi_off, wi0 = wo * p.stride + p.wi_off;
+      a_boff[i] = (((n * p.H + hi0) * p.W + wi0) * p.Cin + scc * CH) * ES;
+      for (int t = 0; t < p.ntaps; ++t) {
+        const i32x4 e = ktab_c[t * 4];
+        if ((unsigned)(hi0 + e[0]) < (unsigned)p.H && (unsigned)(wi0 + e[1]) < (unsigned)p.W) a_okm[i] |= 1u << t;
+      }
+    }
+  }
+  const int w_boff = ((n0 + wave * 16 + srow) * p.Kpad + scc * CH) * ES;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
+  unsigned char* const lds_sa = smem + wave * 2048;             // this wave's 2 KiB of an A plane
+  unsigned char* const lds_sb = smem + A_PLANE + wave * 1024;   // this wave's 1 KiB of a B plane
+
+  f32x4 acc[TC][TP];
+#pragma unroll
+  for (int i = 0; i < TC; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+  const int rd_off = fr * 64 + ((fq ^ swz(fr)) << 4);
+  const unsigned char* const rd_a = smem + (wp * TP * 16) * 64 + rd_off;
+  const unsigned char* const rd_b = smem + A_PLANE + (wc * TC * 16) * 64 + rd_off;
+
+  const int ns = p.n_ktiles * 2;
+
+  // stage plane S into ring slot SLOT_IDX (3 LDS-DMA pieces per wave)
+  auto stage = [&](int S, int slot_idx, const i32x4 e) __attribute__((always_inline)) {
+    const int tap_boff = ((e[0] * p.W + e[1]) * p.Cin + e[2]) * ES;
+    const unsigned tapbit = (e[3] & 1) ? (1u << (e[3] >> 8)) : 0u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = (a_okm[i] & tapbit) ? (a_boff[i] + tap_boff) : (int)0x80000000;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(lds_sa + slot_idx * SLOT + i * 1024), 16, off, 0, 0, 0);
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DP_LDS_PTR(lds_sb + slot_idx * SLOT), 16, w_boff + S * PE * ES, 0, 0, 0);
+  };
+
+  stage(0, 0, ktab_c[0]);
+  if (ns > 1) stage(1, 1, ktab_c[4]);
+  i32x4 e_nx = ktab_c[(ns > 2 ? 2 : 0) * 4];
+  int slot_cur = 0;       // ring slot of plane s
+  int slot_fill = 2;      // ring slot of plane s+2 (= slot of plane s-1)
+  for (int s = 0; s < ns; ++s) {
+    // plane s landed once only plane s+1's pieces (3 per wave) may still be in flight
+    if (s + 1 < ns) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // everybody's pieces of plane s are visible; everybody finished reading plane s-1
+    if (s + 2 < ns) {
+      stage(s + 2, slot_fill, e_nx);
+      e_nx = ktab_c[min(s + 3, ns - 1) * 4];
+    }
+    const int so = slot_cur * SLOT;
+    u32x4 fp[TP], fc[TC];
+#pragma unroll
+    for (int i = 0; i < TC; ++i) fc[i] = *reinterpret_cast<const u32x4*>(rd_b + so + i * 16 * 64);
+#pragma unroll
+    for (int j = 0; j < TP; ++j) fp[j] = *reinterpret_cast<const u32x4*>(rd_a + so + j * 16 * 64);
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+      for (int j = 0; j < TP; ++j) Mma<T>::run(fc[i], fp[j], acc[i][j]);
+    slot_cur = slot_cur == kR2Slots - 1 ? 0 : slot_cur + 1;
+    slot_fill = slot_fill == kR2Slots - 1 ? 0 : slot_fill + 1;
+  }
+
+  // ---- epilogue: fp32 staging tile of 128 rows x 128 couts (64 KiB <= the 72 KiB ring), two passes ----
+  float* const stage_t = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    if ((wp >> 1) == pass) {
+      const int r0 = (wp & 1) * TP * 16;
+#pragma unroll
+      for (int j = 0; j < TP; ++j)
+#pragma unroll
+        for (int i = 0; i < TC; ++i) park_acc<BN>(stage_t, r0 + j * 16 + fr, wc * TC * 16 + i * 16 + fq * 4, acc[i][j]);
+    }
+    __syncthreads();
+    drain_rows<T, BN, NT>(p, stage_t, 128, m0 + pass * 128, n0, tid);
+  }
+}
+
+template <typename T>
+int launch_conv_ring2(const ConvArgs& a, hipStream_t stream) {
+  constexpr int lds = kR2Slots * (256 + 128) * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring2_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_ring2_kernel<T>), dim3(a.n_tiles), dim3(512), lds, stream, a);
+  return dp_check_launch("conv_ring2_kernel");
+}
+
 }  // namespace
 
 // Kernel choice (measured on MI355X, profiles/): the LDS-ring kernels need a 64-byte K plane to lie inside one tap;
 // the 256x256 ring tile is ~1.15x the 128x128 ring tile when both fill the chip, so the shape is picked by
 // wave-quantisation efficiency (workgroups / (CUs x resident workgroups per CU), rounded up to whole rounds);
 // short-K layers are HBM/latency bound and run on the generic kernel with 64-byte steps (4 workgroups per CU).
-enum { DP_CONV_K64 = 0, DP_CONV_K128 = 1, DP_CONV_RING256 = 2, DP_CONV_RING128 = 3 };
+enum { DP_CONV_K64 = 0, DP_CONV_K128 = 1, DP_CONV_RING256 = 2, DP_CONV_RING128 = 3, DP_CONV_RING256x128 = 4 };
 
 static int num_cus() {
   static int n = 0;
@@ -635,19 +786,37 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
     const int f = atoi(fe);
     if (f == 1 && big_ok) return DP_CONV_RING256;
     if (f == 2 && ring_ok) return DP_CONV_RING128;
+    if (f == 3 && ring_ok && p->Cout > 64) return DP_CONV_RING256x128;
     return DP_CONV_K128;
   }
   if (!ring_ok) return DP_CONV_K128;
   if ((long long)p->Kpad * es < 1024) return DP_CONV_K128;   // short K: see above
-  const double cus = (double)num_cus();
-  const double ts = (double)((M + 127) / 128) * ((p->Cout + 127) / 128);
-  const double rs = ts / (2.0 * cus);
-  const double eff_s = rs / (double)(long long)(rs + 0.999999);
+  // Calibrated on the real layer shapes (scratch/conv_sweep.py, MI355X): the 256x256 ring tile wins whenever it has at
+  // least ~half a chip of tiles, even with a ragged last round (fewer resident workgroups run faster), except when the last
+  // round is almost empty (p3-level 3x3: 525 tiles), where the 256x128 two-workgroup tile is ~7 % faster; small-M layers
+  // (res5, p5, fully-connected: M <= 8400) need the 128x128 tile to occupy the chip at all.
+  const char* pe = getenv("DP_CONV_POLICY");  // A/B knob for the calibration runs
+  const int policy = pe ? atoi(pe) : 1;
+  if (policy == 0) {  // round-1 "a" policy: wave-quantisation estimate only
+    const double cus = (double)num_cus();
+    const double ts = (double)((M + 127) / 128) * ((p->Cout + 127) / 128);
+    const double rs = ts / (2.0 * cus);
+    const double eff_s = rs / (double)(long long)(rs + 0.999999);
+    if (big_ok) {
+      const double tb = (double)((M + 255) / 256) * (p->Cout / 256);
+      const double rb = tb / cus;
+      const double eff_b = rb / (double)(long long)(rb + 0.999999);
+      if (1.15 * eff_b > eff_s) return DP_CONV_RING256;
+    }
+    return DP_CONV_RING128;
+  }
   if (big_ok) {
-    const double tb = (double)((M + 255) / 256) * (p->Cout / 256);
-    const double rb = tb / cus;
-    const double eff_b = rb / (double)(long long)(rb + 0.999999);
-    if (1.15 * eff_b > eff_s) return DP_CONV_RING256;
+    const long long t256 = ((M + 255) / 256) * (p->Cout / 256);
+    if (t256 >= 132) {
+      const long long rem = t256 % num_cus();
+      if (policy == 1 && t256 < 4ll * num_cus() && rem >= 1 && rem <= num_cus() / 6) return DP_CONV_RING256x128;
+      return DP_CONV_RING256;
+    }
   }
   return DP_CONV_RING128;
 }
@@ -689,6 +858,11 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
     a.tiles_n = p->Cout / 256;
     a.n_tiles = (int)((M + 255) / 256) * a.tiles_n;
     return p->dtype == DP_F32 ? launch_conv_ring<float, 4, 8>(a, s) : launch_conv_ring<uint16_t, 4, 8>(a, s);
+  }
+  if (kc == DP_CONV_RING256x128) {
+    a.tiles_n = (p->Cout + 127) / 128;
+    a.n_tiles = (int)((M + 255) / 256) * a.tiles_n;
+    return p->dtype == DP_F32 ? launch_conv_ring2<float>(a, s) : launch_conv_ring2<uint16_t>(a, s);
   }
   if (kc == DP_CONV_RING128) {
     a.tiles_n = (p->Cout + 127) / 128;

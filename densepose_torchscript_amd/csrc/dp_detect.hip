@@ -160,7 +160,12 @@ struct RpnSelArgs {
   int32_t* cand_valid;
 };
 
-__global__ __launch_bounds__(kSelThreads) void rpn_select_kernel(const RpnSelArgs p) {
+struct RpnSelMulti {
+  RpnSelArgs lv[5];
+};
+
+__global__ __launch_bounds__(kSelThreads) void rpn_select_kernel(const RpnSelMulti pm) {
+  const RpnSelArgs& p = pm.lv[blockIdx.y];  // one workgroup per (image, level): all levels of a batch in ONE launch
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem_raw);  // [n2]
   __shared__ unsigned int hist[256];
@@ -493,11 +498,12 @@ struct RoiArgs {
   void* out;
   int compact;
   const int32_t* roi_offsets;
+  int items_per_block;
 };
 
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs p) {
-  const int img = blockIdx.z, j = blockIdx.y, py = blockIdx.x;
+  const int img = blockIdx.z, j = blockIdx.y;
   if (j >= p.counts[img]) return;
   const float* b = p.boxes + ((long long)img * p.max_rois + j) * 4;
   const float bx1 = b[0], by1 = b[1], bx2 = b[2], by2 = b[3];
@@ -519,38 +525,48 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs p) {
   const float bin_h = roi_h / (float)P, bin_w = roi_w / (float)P;
   const float count = (float)(g * g > 1 ? g * g : 1);
   const long long orow = p.compact ? (long long)(p.roi_offsets[img] + j) : ((long long)img * p.max_rois + j);
-  T* __restrict__ out = reinterpret_cast<T*>(p.out) + (orow * P + py) * (long long)P * C;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int C4 = C >> 2;
-  for (int px = wave; px < P; px += 4) {
-    for (int c4 = lane; c4 < C4; c4 += 64) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int iy = 0; iy < g; ++iy) {
-        const float yy = rsh + (float)py * bin_h + ((float)iy + 0.5f) * bin_h / (float)g;
-        for (int ix = 0; ix < g; ++ix) {
-          const float xx = rsw + (float)px * bin_w + ((float)ix + 0.5f) * bin_w / (float)g;
-          float y = yy, x = xx;
-          if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;  // contributes 0
-          if (y <= 0.f) y = 0.f;
-          if (x <= 0.f) x = 0.f;
-          int y_low = (int)y, x_low = (int)x, y_high, x_high;
-          if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else { y_high = y_low + 1; }
-          if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else { x_high = x_low + 1; }
-          const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
-          const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-          const float4 v1 = load4(feat + ((long long)y_low * W + x_low) * C + c4 * 4);
-          const float4 v2 = load4(feat + ((long long)y_low * W + x_high) * C + c4 * 4);
-          const float4 v3 = load4(feat + ((long long)y_high * W + x_low) * C + c4 * 4);
-          const float4 v4 = load4(feat + ((long long)y_high * W + x_high) * C + c4 * 4);
-          acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
-          acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
-          acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
-          acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
-        }
+  T* __restrict__ out = reinterpret_cast<T*>(p.out) + orow * (long long)P * P * C;
+  // work item = (bin column px, 8-channel group): 16-byte (bf16) / 32-byte (fp32) vector per corner, so the 7 bins x 32
+  // groups of a box-head row fill one 256-thread pass and every corner read is a full 16-byte lane access
+  // one workgroup per (ROI, slab of bins): ~2048 (bin, 8-channel group) items per workgroup - enough work per thread
+  // to amortise the block's start-up and keep several independent corner loads in flight, while a 28x28 DensePose
+  // pooling of a handful of ROIs still spreads over the whole chip
+  const int C8 = C >> 3;
+  const int item0 = blockIdx.x * p.items_per_block;
+  const int item1 = min(P * P * C8, item0 + p.items_per_block);
+  for (int item = item0 + threadIdx.x; item < item1; item += blockDim.x) {
+    const int bin = item / C8, c8 = item - bin * C8;
+    const int py = bin / P, px = bin - py * P;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int iy = 0; iy < g; ++iy) {
+      const float yy = rsh + (float)py * bin_h + ((float)iy + 0.5f) * bin_h / (float)g;
+      for (int ix = 0; ix < g; ++ix) {
+        const float xx = rsw + (float)px * bin_w + ((float)ix + 0.5f) * bin_w / (float)g;
+        float y = yy, x = xx;
+        if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;  // contributes 0
+        if (y <= 0.f) y = 0.f;
+        if (x <= 0.f) x = 0.f;
+        int y_low = (int)y, x_low = (int)x, y_high, x_high;
+        if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+        if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+        const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const T* p1 = feat + ((long long)y_low * W + x_low) * C + c8 * 8;
+        const T* p2 = feat + ((long long)y_low * W + x_high) * C + c8 * 8;
+        const T* p3 = feat + ((long long)y_high * W + x_low) * C + c8 * 8;
+        const T* p4 = feat + ((long long)y_high * W + x_high) * C + c8 * 8;
+        float v1[8], v2[8], v3[8], v4[8];
+        load8(p1, v1); load8(p2, v2); load8(p3, v3); load8(p4, v4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += w1 * v1[k] + w2 * v2[k] + w3 * v3[k] + w4 * v4[k];
       }
-      acc.x /= count; acc.y /= count; acc.z /= count; acc.w /= count;
-      store4(out + (long long)px * C + c4 * 4, acc);
     }
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = acc[k] / count;
+    store8(out + (long long)bin * C + c8 * 8, r);
   }
 }
 
@@ -627,8 +643,9 @@ extern "C" int64_t dp_rpn_topk_workspace_bytes(int n_img, int Hi, int Wi, int A)
   return (int64_t)n_img * Hi * Wi * A * 8 + 256;
 }
 
-extern "C" int dp_rpn_topk_decode(const dp_rpn_level_params* p, dp_stream_t stream) {
-  DP_REQUIRE(p, "dp_rpn_topk_decode: null params");
+namespace {
+// validates one level, launches its key extraction / chunk pre-selection, fills the select-kernel arguments
+int rpn_prepare_level(const dp_rpn_level_params* p, hipStream_t s, RpnSelArgs& a, int& n2) {
   DP_REQUIRE(p->head && p->cand_boxes && p->cand_scores && p->cand_level && p->cand_valid && p->workspace, "dp_rpn_topk_decode: null pointer");
   DP_REQUIRE(p->n_img > 0 && p->Hi > 0 && p->Wi > 0 && p->A > 0 && p->A <= 3 && p->head_c >= 5 * p->A, "dp_rpn_topk_decode: bad shape");
   DP_REQUIRE(p->kmax > 0 && p->kmax <= 4096, "dp_rpn_topk_decode: kmax=%d outside (0, 4096]", p->kmax);
@@ -636,8 +653,6 @@ extern "C" int dp_rpn_topk_decode(const dp_rpn_level_params* p, dp_stream_t stre
   DP_REQUIRE(p->n_img <= 65535, "dp_rpn_topk_decode: n_img");
   const long long n = (long long)p->Hi * p->Wi * p->A;
   DP_REQUIRE(n < (1ll << 30), "dp_rpn_topk_decode: level too large");
-  hipStream_t s = as_stream(stream);
-  RpnSelArgs a;
   a.head = p->head; a.n_img = p->n_img; a.Hi = p->Hi; a.Wi = p->Wi; a.A = p->A; a.head_c = p->head_c;
   a.stride_px = p->stride_px; a.level = p->level; a.kmax = p->kmax; a.slot_off = p->slot_off; a.slots_per_img = p->slots_per_img;
   for (int i = 0; i < 3; ++i)
@@ -662,9 +677,30 @@ extern "C" int dp_rpn_topk_decode(const dp_rpn_level_params* p, dp_stream_t stre
     a.keys = ws; a.kidx = nullptr; a.n_keys = (int)n;
   }
   const int k = (int)(n < p->kmax ? n : p->kmax);
-  const int n2 = next_pow2(k);
-  hipLaunchKernelGGL(rpn_select_kernel, dim3(p->n_img), dim3(kSelThreads), n2 * 8, s, a);
+  n2 = next_pow2(k);
+  return DP_OK;
+}
+}  // namespace
+
+extern "C" int dp_rpn_topk_decode_levels(const dp_rpn_level_params* levels, int n_levels, dp_stream_t stream) {
+  DP_REQUIRE(levels && n_levels >= 1 && n_levels <= 5, "dp_rpn_topk_decode_levels: 1..5 levels");
+  hipStream_t s = as_stream(stream);
+  RpnSelMulti m;
+  int n2max = 1;
+  for (int l = 0; l < n_levels; ++l) {
+    DP_REQUIRE(levels[l].n_img == levels[0].n_img, "dp_rpn_topk_decode_levels: all levels must share n_img");
+    int n2 = 1;
+    const int rc = rpn_prepare_level(&levels[l], s, m.lv[l], n2);
+    if (rc != DP_OK) return rc;
+    if (n2 > n2max) n2max = n2;
+  }
+  hipLaunchKernelGGL(rpn_select_kernel, dim3(levels[0].n_img, n_levels), dim3(kSelThreads), n2max * 8, s, m);
   return dp_check_launch("rpn_select_kernel");
+}
+
+extern "C" int dp_rpn_topk_decode(const dp_rpn_level_params* p, dp_stream_t stream) {
+  DP_REQUIRE(p, "dp_rpn_topk_decode: null params");
+  return dp_rpn_topk_decode_levels(p, 1, stream);
 }
 
 extern "C" int64_t dp_nms_workspace_bytes(int n_img, int n_slots) {
@@ -705,7 +741,7 @@ extern "C" int dp_roi_align_nhwc(const dp_roi_align_params* p, dp_stream_t strea
   DP_REQUIRE(p, "dp_roi_align_nhwc: null params");
   DP_REQUIRE(p->boxes && p->counts && p->out, "dp_roi_align_nhwc: null pointer");
   DP_REQUIRE(p->n_levels == 1 || p->n_levels == 4, "dp_roi_align_nhwc: n_levels=%d", p->n_levels);
-  DP_REQUIRE(p->n_img > 0 && p->max_rois > 0 && p->C > 0 && p->C % 4 == 0 && p->P > 0 && p->sampling > 0, "dp_roi_align_nhwc: bad shape");
+  DP_REQUIRE(p->n_img > 0 && p->max_rois > 0 && p->C > 0 && p->C % 8 == 0 && p->P > 0 && p->sampling > 0, "dp_roi_align_nhwc: bad shape");
   DP_REQUIRE(!p->compact || p->roi_offsets, "dp_roi_align_nhwc: compact mode needs roi_offsets");
   RoiArgs a;
   for (int i = 0; i < 4; ++i) {
@@ -717,7 +753,10 @@ extern "C" int dp_roi_align_nhwc(const dp_roi_align_params* p, dp_stream_t strea
   a.boxes = p->boxes; a.counts = p->counts; a.n_img = p->n_img; a.max_rois = p->max_rois; a.out = p->out;
   a.compact = p->compact; a.roi_offsets = p->roi_offsets;
   hipStream_t s = as_stream(stream);
-  const dim3 grid(p->P, p->max_rois, p->n_img), block(256);
+  const int C8 = p->C / 8;
+  const int bins_per_block = 2048 / C8 > 0 ? 2048 / C8 : 1;
+  a.items_per_block = bins_per_block * C8;
+  const dim3 grid((p->P * p->P + bins_per_block - 1) / bins_per_block, p->max_rois, p->n_img), block(256);
   if (p->dtype == DP_F32) hipLaunchKernelGGL(roi_align_kernel<float>, grid, block, 0, s, a);
   else if (p->dtype == DP_BF16) hipLaunchKernelGGL(roi_align_kernel<uint16_t>, grid, block, 0, s, a);
   else return dp_fail(DP_ERR_BAD_ARG, "dp_roi_align_nhwc: bad dtype");

@@ -110,7 +110,7 @@ class Engine:
             e0.record()
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
             e1.record()
-            cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_ring_kernel<256x256>", "conv_ring_kernel<128x128>")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
+            cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_ring_kernel<256x256>", "conv_ring_kernel<128x128>", "conv_ring2_kernel<256x128>")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
             self.prof.append((cls, flops, e0, e1, layer.name))
         else:
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
@@ -172,15 +172,16 @@ class Engine:
         cand_level = self._empty((n, slots), torch.int32)
         cand_valid = self._empty((n, slots), torch.int32)
         A = len(cfg.anchor_ratios)
-        ws_bytes = max(self.lib.dp_rpn_topk_workspace_bytes(n, feats[k].H, feats[k].W, A) for k in ("p2", "p3", "p4", "p5", "p6"))
-        ws = self._empty((ws_bytes,), torch.uint8)
-        heads = []
+        levels = (L.RpnLevelParams * nl)()
+        heads, wss = [], []
         for li, k in enumerate(("p2", "p3", "p4", "p5", "p6")):
             f = feats[k]
             t = self.conv(Ls["rpn_conv"], f, relu=True)
             head = self.conv(Ls["rpn_head"], t, out_f32=True)
             heads.append(head)
-            p = L.RpnLevelParams()
+            ws = self._empty((self.lib.dp_rpn_topk_workspace_bytes(n, f.H, f.W, A),), torch.uint8)
+            wss.append(ws)
+            p = levels[li]
             p.head = head.t.data_ptr()
             p.n_img, p.Hi, p.Wi, p.A, p.head_c = n, f.H, f.W, A, head.C
             p.stride_px = FPN_STRIDES[li]
@@ -192,7 +193,8 @@ class Engine:
             p.cand_boxes, p.cand_scores = cand_boxes.data_ptr(), cand_scores.data_ptr()
             p.cand_level, p.cand_valid = cand_level.data_ptr(), cand_valid.data_ptr()
             p.workspace = ws.data_ptr()
-            L.check(self.lib.dp_rpn_topk_decode(C.byref(p), self._stream()), "dp_rpn_topk_decode")
+        # top-k + decode of all five levels in one select launch (one workgroup per image and level)
+        L.check(self.lib.dp_rpn_topk_decode_levels(levels, nl, self._stream()), "dp_rpn_topk_decode_levels")
         post = cfg.rpn_post_topk
         props, scores, _, counts = self.nms(cand_boxes, cand_scores, cand_level, cand_valid, n, slots, cfg.rpn_nms_thresh, post)
         if self.keep_intermediates:

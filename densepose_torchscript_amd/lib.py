@@ -108,6 +108,7 @@ SYMBOLS = {
     "dp_merge_upsample2x_nhwc": (c_int, [c_void_p, C.POINTER(c_void_p), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_rpn_topk_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
     "dp_rpn_topk_decode": (c_int, [C.POINTER(RpnLevelParams), c_void_p]),
+    "dp_rpn_topk_decode_levels": (c_int, [C.POINTER(RpnLevelParams), c_int, c_void_p]),
     "dp_nms_workspace_bytes": (c_i64, [c_int, c_int]),
     "dp_batched_nms": (c_int, [C.POINTER(NmsParams), c_void_p]),
     "dp_roi_align_nhwc": (c_int, [C.POINTER(RoiAlignParams), c_void_p]),

@@ -124,6 +124,8 @@ typedef struct {
 } dp_rpn_level_params;
 int64_t dp_rpn_topk_workspace_bytes(int n_img, int Hi, int Wi, int A);
 int dp_rpn_topk_decode(const dp_rpn_level_params* p, dp_stream_t stream);
+/* all (<= 5) FPN levels of a batch in one select launch; every level needs its OWN workspace */
+int dp_rpn_topk_decode_levels(const dp_rpn_level_params* levels, int n_levels, dp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K10/K13  nms.py:20 -> torchvision batched_nms + keep[:post_topk]  (proposal_utils.py:118-126,

@@ -58,7 +58,7 @@ BIG_CASES = [
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-@pytest.mark.parametrize("force", ["1", "2"])   # 1: 256x256 ring kernel, 2: 128x128 ring kernel
+@pytest.mark.parametrize("force", ["1", "2", "3"])   # 1: 256x256 ring kernel, 2: 128x128 ring kernel, 3: 256x128 two-WG ring kernel
 @pytest.mark.parametrize("case", BIG_CASES)
 def test_conv2d_ring_kernels(eng, dt, case, force, monkeypatch):
     monkeypatch.setenv("DP_CONV_BIG", force)
