@@ -21,7 +21,7 @@ from .weights import check_state, load_checkpoint
 
 
 class DensePosePredictor:
-    def __init__(self, cfg, weights, dtype="bf16", device="cuda:0", resize="host", num_streams=2, use_graphs=False):
+    def __init__(self, cfg, weights, dtype="bf16", device="cuda:0", resize="host", num_streams=2, use_graphs=False, check_keep=False):
         """cfg: ModelConfig | variant name | yaml path. weights: path to .pkl/.pth or a canonical state dict."""
         if not isinstance(cfg, ModelConfig):
             cfg = get_config(cfg)
@@ -37,6 +37,11 @@ class DensePosePredictor:
         self.resize_mode = resize  # "host": torch CPU uint8 kernel exactly as the reference (Q4) ; "device": HIP kernel
         self.num_streams = num_streams  # sub-batches of a batch run concurrently on this many HIP streams
         self.engine.use_graphs = use_graphs  # replay the static part of the path (backbone .. detection select) as a HIP graph
+        # postprocessing.py:51 drops boxes with negative extent after rescaling. That cannot happen on this path: decoded
+        # boxes have w = exp(dw) * w_src >= 0 (box_regression.py:104-105), clipping and the positive rescale are monotonic,
+        # non-finite boxes were filtered before NMS. The flags are still computed on the device; reading them back costs a
+        # device synchronisation per batch, so it is opt-in (tests run with check_keep=True).
+        self.check_keep = check_keep
 
     # -- defaults.py:76-89 ---------------------------------------------------------------------------------
     def _to_chw(self, original_image, bgr):
@@ -81,7 +86,8 @@ class DensePosePredictor:
             batch = torch.stack([resized[i] for i in idxs])
             orig = [(int(chws[i].shape[1]), int(chws[i].shape[2])) for i in idxs]
             res = self.engine.forward_batch(batch, orig, num_streams=self.num_streams if len(idxs) >= 4 else 1)
-            res = self.engine.apply_keep_filter(res)
+            if self.check_keep:
+                res = self.engine.apply_keep_filter(res)
             for i, r in zip(idxs, res):
                 out[i] = r
         return out

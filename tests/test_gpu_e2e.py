@@ -22,7 +22,7 @@ def _run(name, dtype="fp32", keep=False, resize="host"):
     from densepose_torchscript_amd.predictor import DensePosePredictor
     meta, z = load_golden(name)
     cfg, state, img = golden_case_inputs(meta)
-    pred = DensePosePredictor(cfg, state, dtype=dtype, resize=resize)
+    pred = DensePosePredictor(cfg, state, dtype=dtype, resize=resize, check_keep=True)
     pred.engine.keep_intermediates = keep
     out = pred(torch.from_numpy(img))
     torch.cuda.synchronize()
