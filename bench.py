@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--config", default="densepose_rcnn_R_50_FPN_s1x")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--dets", type=int, default=8, help="detections per image (R), pinned via TEST.DETECTIONS_PER_IMAGE")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
@@ -153,7 +153,7 @@ def main():
     torch.cuda.synchronize()
     t_ser = (time.perf_counter() - t_ser) / args.steps
     agg = {}
-    for cls, flops, e0, e1, name in eng.prof:
+    for cls, flops, e0, e1, name, _ in eng.prof:
         a = agg.setdefault(cls, [0, 0.0, 0])
         a[0] += flops
         a[1] += e0.elapsed_time(e1) * 1e-3
@@ -162,7 +162,7 @@ def main():
     pred.num_streams, eng.use_graphs = args.streams, not args.no_graphs
     dom = max(agg, key=lambda c: agg[c][1])
     dflops, dsec, dcalls = agg[dom]
-    peak = PEAK_BF16_DENSE if args.dtype == "bf16" else PEAK_F32_MATRIX
+    peak = PEAK_F32_MATRIX if args.dtype == "fp32" else PEAK_BF16_DENSE  # fp16 and bf16 MFMA share the dense peak
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
     if os.path.exists(tpath) and args.dtype == "bf16" and args.config == "densepose_rcnn_R_50_FPN_s1x" and args.batch == 8:
@@ -188,7 +188,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.dtype], "data": "synthetic",
             "p50_ms_per_img": round(1e3 * float(np.median(step_times)) / args.batch, 3),
             "config": {"workload": "%s batch=%d/GPU %dx%d uint8 frames resident in HBM, R=%d detections/img (measured %s), synthetic seeded weights"
                                    % (args.config, args.batch, hw[0], hw[1], args.dets, dets),

@@ -26,15 +26,25 @@ inline int dp_check_launch(const char* what) {
   return DP_OK;
 }
 
-// ---- bf16 <-> f32 (device) -----------------------------------------------------------------------
+// ---- 16-bit storage <-> f32 (device) ---------------------------------------------------------------
+// Storage types: float, uint16_t (= bf16 bit pattern) and f16_t (IEEE half, reference `.half()` mode
+// /root/reference/export.py:36-37). Arithmetic outside the MFMA operands is always fp32.
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) { return __builtin_bit_cast(float, lo16 << 16); }
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
   // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
   bf16_t ha = (bf16_t)a, hb = (bf16_t)b;
+  return (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t lo16) { return (float)__builtin_bit_cast(f16_t, (uint16_t)lo16); }
+__device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
+  // RNE like torch's .half(); values beyond 65504 become inf exactly as they do in the reference's fp16 mode
+  f16_t ha = (f16_t)a, hb = (f16_t)b;
   return (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
 }
 
@@ -46,6 +56,8 @@ struct Elem<float> {
   static constexpr int kChunk = 4;  // elements per 16-byte chunk
   __device__ static __forceinline__ float load(const float* p) { return *p; }
   __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+  __device__ static __forceinline__ uint32_t pack2(float, float) { return 0u; }  // never used: fp32 is stored unpacked
+  __device__ static __forceinline__ float unpack(uint32_t) { return 0.f; }
 };
 template <>
 struct Elem<uint16_t> {  // bf16 storage
@@ -56,38 +68,54 @@ struct Elem<uint16_t> {  // bf16 storage
     bf16_t h = (bf16_t)v;
     *p = __builtin_bit_cast(uint16_t, h);
   }
+  __device__ static __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
+  __device__ static __forceinline__ float unpack(uint32_t lo16) { return bf16_bits_to_f32(lo16); }
+};
+template <>
+struct Elem<f16_t> {  // IEEE half storage
+  static constexpr int kDtype = DP_F16;
+  static constexpr int kChunk = 8;
+  __device__ static __forceinline__ float load(const f16_t* p) { return (float)*p; }
+  __device__ static __forceinline__ void store(f16_t* p, float v) { *p = (f16_t)v; }
+  __device__ static __forceinline__ uint32_t pack2(float a, float b) { return pack_f16x2(a, b); }
+  __device__ static __forceinline__ float unpack(uint32_t lo16) { return f16_bits_to_f32(lo16); }
 };
 
-// load / store 4 consecutive channels (8-byte aligned for bf16, 16-byte for f32)
+// load / store 4 consecutive channels (8-byte aligned for 16-bit storage, 16-byte for f32)
 __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float4 load4(const uint16_t* p) {
-  uint2 u = *reinterpret_cast<const uint2*>(p);
-  return make_float4(bf16_bits_to_f32(u.x & 0xffffu), bf16_bits_to_f32(u.x >> 16), bf16_bits_to_f32(u.y & 0xffffu),
-                     bf16_bits_to_f32(u.y >> 16));
+template <typename T>
+__device__ __forceinline__ float4 load4(const T* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(Elem<T>::unpack(u.x & 0xffffu), Elem<T>::unpack(u.x >> 16), Elem<T>::unpack(u.y & 0xffffu),
+                     Elem<T>::unpack(u.y >> 16));
 }
 __device__ __forceinline__ void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ void store4(uint16_t* p, float4 v) {
-  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+template <typename T>
+__device__ __forceinline__ void store4(T* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(Elem<T>::pack2(v.x, v.y), Elem<T>::pack2(v.z, v.w));
 }
 
-// 8 consecutive channels: ONE 16-byte access for bf16, two for f32
+// 8 consecutive channels: ONE 16-byte access for 16-bit storage, two for f32
 __device__ __forceinline__ void load8(const float* p, float (&o)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
 }
-__device__ __forceinline__ void load8(const uint16_t* p, float (&o)[8]) {
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&o)[8]) {
   const uint4 u = *reinterpret_cast<const uint4*>(p);
-  o[0] = bf16_bits_to_f32(u.x & 0xffffu); o[1] = bf16_bits_to_f32(u.x >> 16);
-  o[2] = bf16_bits_to_f32(u.y & 0xffffu); o[3] = bf16_bits_to_f32(u.y >> 16);
-  o[4] = bf16_bits_to_f32(u.z & 0xffffu); o[5] = bf16_bits_to_f32(u.z >> 16);
-  o[6] = bf16_bits_to_f32(u.w & 0xffffu); o[7] = bf16_bits_to_f32(u.w >> 16);
+  o[0] = Elem<T>::unpack(u.x & 0xffffu); o[1] = Elem<T>::unpack(u.x >> 16);
+  o[2] = Elem<T>::unpack(u.y & 0xffffu); o[3] = Elem<T>::unpack(u.y >> 16);
+  o[4] = Elem<T>::unpack(u.z & 0xffffu); o[5] = Elem<T>::unpack(u.z >> 16);
+  o[6] = Elem<T>::unpack(u.w & 0xffffu); o[7] = Elem<T>::unpack(u.w >> 16);
 }
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
-__device__ __forceinline__ void store8(uint16_t* p, const float (&v)[8]) {
-  *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3]), Elem<T>::pack2(v[4], v[5]),
+                                            Elem<T>::pack2(v[6], v[7]));
 }
 
 static inline hipStream_t as_stream(dp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

@@ -63,6 +63,12 @@ struct Mma<uint16_t> {
   }
 };
 template <>
+struct Mma<f16_t> {
+  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
 struct Mma<float> {
   __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
     // whole-vector bit_cast, then index: bit_cast of a single ext-vector element (a.y ...) silently read element 0
@@ -75,87 +81,72 @@ struct Mma<float> {
 };
 
 
-// ---- LDS-staged epilogue -------------------------------------------------------------------------------------
-// The accumulators (4 consecutive channels of one pixel per lane) are parked in LDS as an fp32 [rows][COLS] tile
-// (16-byte chunks XOR-swizzled by row so that the ds_write_b128 of 8 consecutive rows hits 8 different slots), then
-// read back row-major: each lane owns 8 consecutive channels of one pixel -> bias/residual/ReLU in fp32, ONE 16-byte
-// (bf16) or two 16-byte (fp32) stores, 16 lanes covering 256 contiguous bytes of the NHWC row (full 128-B lines
-// instead of four 32-byte fragments per line: the direct epilogue was store-issue bound).
-template <int COLS>
-__device__ __forceinline__ void park_acc(float* lds, int row, int col, const f32x4& v) {
-  const int chunk = (col >> 2) ^ (row & 7);
-  *reinterpret_cast<f32x4*>(lds + row * COLS + chunk * 4) = v;
-}
-
-template <typename T, int COLS, int NTHREADS>
-__device__ __forceinline__ void drain_rows(const ConvArgs& p, const float* lds, int rows, int m_base, int n_base, int tid) {
-  constexpr int LPR = COLS / 8;              // lanes per pixel row
-  constexpr int RPP = NTHREADS / LPR;        // rows per pass
-  static_assert(RPP % 8 == 0, "the row swizzle (r & 7) must be the same for every row a thread drains");
-  const int q = tid % LPR;                   // 8-channel group inside the tile
-  const int r0 = tid / LPR;
-  const int co = n_base + q * 8;
-  if (co >= p.Cout) return;
-  const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + co);
-  const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + co + 4);
+// ---- register epilogue ----------------------------------------------------------------------------------------
+// Every kernel below gives a wave 64 couts (four 16x16 MFMA tiles i = 0..3 along cout, weights as the A operand) x TP
+// pixel tiles, so lane (fr = lane & 15, fq = lane >> 4) holds rows fq*4 .. fq*4+3 of each cout tile for pixel fr of each
+// pixel tile. pack.py stores the weight rows of every 64-cout block PERMUTED - physical row i*16 + fq*4 + e carries
+// logical cout (i>>1)*32 + fq*8 + (i&1)*4 + e - so those 16 accumulator rows are two runs of 8 CONSECUTIVE output
+// channels of one pixel. Bias / residual / ReLU / convert happen in registers and each lane writes 16-byte pieces, the
+// four lanes of a pixel covering 64 contiguous bytes of the NHWC row per instruction: no LDS staging tile, no barrier,
+// and the operand ring stays free for the next tile.
+template <typename T, int TP>
+__device__ __forceinline__ void store_tile(const ConvArgs& p, const f32x4 (&acc)[4][TP], int m_wave, int n_wave, int fr, int fq) {
   const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
-  const int nrows = min(rows, p.M - m_base);
-  const int sw = r0 & 7;
-  const float* l0 = lds + r0 * COLS + ((2 * q) ^ sw) * 4;
-  const float* l1 = lds + r0 * COLS + ((2 * q + 1) ^ sw) * 4;
   const bool f32_out = p.out_f32 || sizeof(T) == 4;
-
-  auto finish = [&](f32x4 v0, f32x4 v1, const T* rp, void* op) __attribute__((always_inline)) {
-    v0 += b0;
-    v1 += b1;
-    if (rp) {
-      const float4 ra = load4(rp), rc = load4(rp + 4);
-      v0[0] += ra.x; v0[1] += ra.y; v0[2] += ra.z; v0[3] += ra.w;
-      v1[0] += rc.x; v1[1] += rc.y; v1[2] += rc.z; v1[3] += rc.w;
-    }
-    if (p.relu) {
+  const bool linear = p.out_linear && (!res || p.res_linear);
+  float bias[2][8];
+  bool live[2];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { v0[k] = fmaxf(v0[k], 0.f); v1[k] = fmaxf(v1[k], 0.f); }
-    }
-    if (f32_out) {
-      float* o = reinterpret_cast<float*>(op);
-      *reinterpret_cast<f32x4*>(o) = v0;
-      *reinterpret_cast<f32x4*>(o + 4) = v1;
-    } else {
-      u32x4 pk;
-      pk[0] = pack_bf16x2(v0[0], v0[1]); pk[1] = pack_bf16x2(v0[2], v0[3]);
-      pk[2] = pack_bf16x2(v1[0], v1[1]); pk[3] = pack_bf16x2(v1[2], v1[3]);
-      *reinterpret_cast<u32x4*>(op) = pk;
-    }
-  };
-
-  if (p.out_linear && (!res || p.res_linear)) {
-    // plain NHWC tensors: element offset = m * pixel stride -> pointers advance by a constant per row, no integer
-    // division / 64-bit multiply per row (the epilogue was VALU-bound on exactly that)
-    const long long ostep = (long long)RPP * p.osW, rstep = (long long)RPP * p.rsW;
-    const long long o0 = (long long)(m_base + r0) * p.osW + co;
-    unsigned char* op = reinterpret_cast<unsigned char*>(p.out) + o0 * (f32_out ? 4 : (long long)sizeof(T));
-    const long long obytes = ostep * (f32_out ? 4 : (long long)sizeof(T));
-    const T* rp = res ? res + (long long)(m_base + r0) * p.rsW + co : nullptr;
-    for (int r = r0; r < nrows; r += RPP) {
-      finish(*reinterpret_cast<const f32x4*>(l0), *reinterpret_cast<const f32x4*>(l1), rp, op);
-      l0 += RPP * COLS;
-      l1 += RPP * COLS;
-      op += obytes;
-      if (rp) rp += rstep;
-    }
-    return;
+  for (int h = 0; h < 2; ++h) {
+    const int c = n_wave + h * 32 + fq * 8;
+    live[h] = c < p.Cout;   // Cout is a multiple of 8: a run of 8 channels is all in or all out
+    const f32x4 b0 = live[h] ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 b1 = live[h] ? *reinterpret_cast<const f32x4*>(p.bias + c + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { bias[h][k] = b0[k]; bias[h][4 + k] = b1[k]; }
   }
-  for (int r = r0; r < nrows; r += RPP, l0 += RPP * COLS, l1 += RPP * COLS) {
-    const int m = m_base + r;
-    const int n = m / p.HoWo;
-    const int rem = m - n * p.HoWo;
-    const int ho = rem / p.Wo;
-    const int wo = rem - ho * p.Wo;
-    const T* rp = res ? res + (n * p.rsN + (ho >> p.rshift) * p.rsH + (wo >> p.rshift) * p.rsW + co) : nullptr;
-    const long long ob = n * p.osN + ho * p.osH + wo * p.osW + co;
-    void* op = f32_out ? static_cast<void*>(reinterpret_cast<float*>(p.out) + ob) : static_cast<void*>(reinterpret_cast<T*>(p.out) + ob);
-    finish(*reinterpret_cast<const f32x4*>(l0), *reinterpret_cast<const f32x4*>(l1), rp, op);
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    const int m_raw = m_wave + j * 16 + fr;
+    const bool row_ok = m_raw < p.M;
+    const int m = row_ok ? m_raw : p.M - 1;   // loads stay unconditional (clamped row), only the stores are predicated
+    long long ob, rb = 0;
+    if (linear) {
+      ob = (long long)m * p.osW;
+      rb = (long long)m * p.rsW;
+    } else {
+      const int n = m / p.HoWo;
+      const int rem = m - n * p.HoWo;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      ob = n * p.osN + ho * p.osH + wo * p.osW;
+      if (res) rb = n * p.rsN + (ho >> p.rshift) * p.rsH + (wo >> p.rshift) * p.rsW;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (!live[h]) continue;
+      const int c = n_wave + h * 32 + fq * 8;
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[k] = acc[2 * h][j][k] + bias[h][k];
+        v[4 + k] = acc[2 * h + 1][j][k] + bias[h][4 + k];
+      }
+      if (res) {
+        float r[8];
+        load8(res + rb + c, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += r[k];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+      }
+      if (row_ok) {
+        if (f32_out) store8(reinterpret_cast<float*>(p.out) + ob + c, v);
+        else store8(reinterpret_cast<T*>(p.out) + ob + c, v);
+      }
+    }
   }
 }
 
@@ -305,24 +296,8 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs 
     __syncthreads();
   }
 
-  // ---- epilogue (the last loop barrier guarantees every wave is done reading the operand tiles) ----
-  // two passes of 64 pixel rows: the fp32 staging tile then needs only 64 x BN x 4 bytes, so single-K-step layers
-  // (the HBM-bound 1x1s of res2) run with 32 KiB of LDS and four workgroups per CU instead of two
-  float* const stage = reinterpret_cast<float*>(smem);
-  constexpr int W_PER_HALF = WAVES_P / 2;  // pixel-waves per 64-row half
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if (half) __syncthreads();
-    if (wp / W_PER_HALF == half) {
-      const int r0 = (wp % W_PER_HALF) * TP * 16;
-#pragma unroll
-      for (int j = 0; j < TP; ++j)
-#pragma unroll
-        for (int i = 0; i < TC; ++i) park_acc<BN>(stage, r0 + j * 16 + fr, wc * TC * 16 + i * 16 + fq * 4, acc[i][j]);
-    }
-    __syncthreads();
-    drain_rows<T, BN, kThreads>(p, stage, 64, m0 + half * 64, n0, tid);
-  }
+  // ---- epilogue straight from the accumulators ----
+  store_tile<T, TP>(p, acc, m0 + wp * TP * 16, n0 + wc * 64, fr, fq);
 }
 
 #undef DP_STAGE_TILE
@@ -361,7 +336,6 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
   constexpr int PE = 64 / ES;             // elements of K per plane
   constexpr int TC = 4;
   constexpr int NW = WC * 2;              // waves
-  constexpr int NT = NW * 64;
   constexpr int BM = 2 * TP * 16;         // pixels
   constexpr int BN = WC * 64;             // couts
   constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, SLOT = A_PLANE + B_PLANE;
@@ -542,24 +516,8 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
     if (s + 1 < ns) DP_RING_STEP(s + 1, fpB, fcB, fpA, fcA);
   }
 
-  // ---- epilogue through the ring's LDS as an fp32 staging tile of (ring bytes / (BN*4)) pixel rows per pass ----
-  float* const stage = reinterpret_cast<float*>(smem);
-  constexpr int ROWS_PER_PASS = kRing * SLOT / (BN * 4);     // 128 for both shapes
-  constexpr int PASSES = BM / ROWS_PER_PASS;                 // 2 (256-pixel tile) or 1 (128-pixel tile)
-  static_assert(ROWS_PER_PASS == 128 && (PASSES == 1 || PASSES == 2), "staging geometry");
-#pragma unroll
-  for (int pass = 0; pass < PASSES; ++pass) {
-    __syncthreads();  // operands (pass 0) / previous staging tile (pass 1) no longer needed
-    if (PASSES == 1 || wp == pass) {
-      const int r0 = PASSES == 1 ? wp * TP * 16 : 0;
-#pragma unroll
-      for (int j = 0; j < TP; ++j)
-#pragma unroll
-        for (int i = 0; i < TC; ++i) park_acc<BN>(stage, r0 + j * 16 + fr, wc * TC * 16 + i * 16 + fq * 4, acc[i][j]);
-    }
-    __syncthreads();
-    drain_rows<T, BN, NT>(p, stage, ROWS_PER_PASS, m0 + pass * ROWS_PER_PASS, n0, tid);
-  }
+  // ---- epilogue straight from the accumulators ----
+  store_tile<T, TP>(p, acc, m0 + wp * TP * 16, n0 + wc * 64, fr, fq);
 }
 #undef DP_RING_STAGE
 #undef DP_RING_READ
@@ -581,8 +539,7 @@ int launch_conv_ring(const ConvArgs& a, hipStream_t stream) {
 template <typename T, int BN, int NPL>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
   constexpr int buf = NPL * (kBM * 64 + BN * 64);   // one operand stage
-  constexpr int staging = 64 * BN * 4;              // epilogue staging (half tile, fp32)
-  constexpr int full = 2 * buf > staging ? 2 * buf : staging;
+  constexpr int full = 2 * buf;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, BN, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize, full);
@@ -590,7 +547,7 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
   }
   // single-step layers never touch the second stage
   const int steps = a.n_ktiles * (2 / NPL);
-  const int lds = steps == 1 ? (buf > staging ? buf : staging) : full;
+  const int lds = steps == 1 ? buf : full;
   hipLaunchKernelGGL((conv_igemm_kernel<T, BN, NPL>), dim3(a.n_tiles), dim3(kThreads), lds, stream, a);
   return dp_check_launch("conv_igemm_kernel");
 }
@@ -617,7 +574,6 @@ __global__ __launch_bounds__(512, 4) void conv_ring2_kernel(const ConvArgs p) {
   constexpr int TC = 4, TP = 4;
   constexpr int BM = 256, BN = 128;
   constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, SLOT = A_PLANE + B_PLANE;   // 24 KiB
-  constexpr int NT = 512;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -723,21 +679,8 @@ __global__ __launch_bounds__(512, 4) void conv_ring2_kernel(const ConvArgs p) {
     slot_fill = slot_fill == kR2Slots - 1 ? 0 : slot_fill + 1;
   }
 
-  // ---- epilogue: fp32 staging tile of 128 rows x 128 couts (64 KiB <= the 72 KiB ring), two passes ----
-  float* const stage_t = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    __syncthreads();
-    if ((wp >> 1) == pass) {
-      const int r0 = (wp & 1) * TP * 16;
-#pragma unroll
-      for (int j = 0; j < TP; ++j)
-#pragma unroll
-        for (int i = 0; i < TC; ++i) park_acc<BN>(stage_t, r0 + j * 16 + fr, wc * TC * 16 + i * 16 + fq * 4, acc[i][j]);
-    }
-    __syncthreads();
-    drain_rows<T, BN, NT>(p, stage_t, 128, m0 + pass * 128, n0, tid);
-  }
+  // ---- epilogue straight from the accumulators ----
+  store_tile<T, TP>(p, acc, m0 + wp * TP * 16, n0 + wc * 64, fr, fq);
 }
 
 template <typename T>
@@ -826,9 +769,17 @@ extern "C" int dp_conv2d_kernel_class(const dp_conv_params* p) {
   return choose_conv_kernel(p, (long long)p->N * p->Ho * p->Wo);
 }
 
+// evaluates EXPR with the storage type bound to T and returns its value
+#define DP_BY_DTYPE(EXPR)                                  \
+  switch (p->dtype) {                                      \
+    case DP_F32: { using T = float; return EXPR; }         \
+    case DP_BF16: { using T = uint16_t; return EXPR; }     \
+    default: { using T = f16_t; return EXPR; }             \
+  }
+
 extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   DP_REQUIRE(p != nullptr, "dp_conv2d_nhwc: null params");
-  DP_REQUIRE(p->dtype == DP_F32 || p->dtype == DP_BF16, "dp_conv2d_nhwc: bad dtype %d", p->dtype);
+  DP_REQUIRE(p->dtype == DP_F32 || p->dtype == DP_BF16 || p->dtype == DP_F16, "dp_conv2d_nhwc: bad dtype %d", p->dtype);
   const int es = p->dtype == DP_F32 ? 4 : 2;
   DP_REQUIRE(p->N >= 0 && p->H > 0 && p->W > 0 && p->Ho > 0 && p->Wo > 0, "dp_conv2d_nhwc: bad spatial shape");
   const long long M = (long long)p->N * p->Ho * p->Wo;
@@ -857,25 +808,25 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   if (kc == DP_CONV_RING256) {
     a.tiles_n = p->Cout / 256;
     a.n_tiles = (int)((M + 255) / 256) * a.tiles_n;
-    return p->dtype == DP_F32 ? launch_conv_ring<float, 4, 8>(a, s) : launch_conv_ring<uint16_t, 4, 8>(a, s);
+    DP_BY_DTYPE((launch_conv_ring<T, 4, 8>(a, s)));
   }
   if (kc == DP_CONV_RING256x128) {
     a.tiles_n = (p->Cout + 127) / 128;
     a.n_tiles = (int)((M + 255) / 256) * a.tiles_n;
-    return p->dtype == DP_F32 ? launch_conv_ring2<float>(a, s) : launch_conv_ring2<uint16_t>(a, s);
+    DP_BY_DTYPE((launch_conv_ring2<T>(a, s)));
   }
   if (kc == DP_CONV_RING128) {
     a.tiles_n = (p->Cout + 127) / 128;
     a.n_tiles = (int)((M + 127) / 128) * a.tiles_n;
-    return p->dtype == DP_F32 ? launch_conv_ring<float, 2, 4>(a, s) : launch_conv_ring<uint16_t, 2, 4>(a, s);
+    DP_BY_DTYPE((launch_conv_ring<T, 2, 4>(a, s)));
   }
   const int tiles_m = (int)((M + kBM - 1) / kBM);
   if (kc == DP_CONV_K64) {
     a.tiles_n = (p->Cout + 63) / 64;
     a.n_tiles = tiles_m * a.tiles_n;
-    return p->dtype == DP_F32 ? launch_conv_k<float, 64>(a, s) : launch_conv_k<uint16_t, 64>(a, s);
+    DP_BY_DTYPE((launch_conv_k<T, 64>(a, s)));
   }
   a.tiles_n = (p->Cout + 127) / 128;
   a.n_tiles = tiles_m * a.tiles_n;
-  return p->dtype == DP_F32 ? launch_conv_k<float, 128>(a, s) : launch_conv_k<uint16_t, 128>(a, s);
+  DP_BY_DTYPE((launch_conv_k<T, 128>(a, s)));
 }

@@ -759,6 +759,7 @@ extern "C" int dp_roi_align_nhwc(const dp_roi_align_params* p, dp_stream_t strea
   const dim3 grid((p->P * p->P + bins_per_block - 1) / bins_per_block, p->max_rois, p->n_img), block(256);
   if (p->dtype == DP_F32) hipLaunchKernelGGL(roi_align_kernel<float>, grid, block, 0, s, a);
   else if (p->dtype == DP_BF16) hipLaunchKernelGGL(roi_align_kernel<uint16_t>, grid, block, 0, s, a);
+  else if (p->dtype == DP_F16) hipLaunchKernelGGL(roi_align_kernel<f16_t>, grid, block, 0, s, a);
   else return dp_fail(DP_ERR_BAD_ARG, "dp_roi_align_nhwc: bad dtype");
   return dp_check_launch("roi_align_kernel");
 }

@@ -301,8 +301,11 @@ __global__ void broadcast_hw_kernel(const T* __restrict__ in, T* __restrict__ ou
 
 }  // namespace
 
-#define DISPATCH_DTYPE(dtype, KERNEL_CALL_F32, KERNEL_CALL_BF16)                 \
-  if ((dtype) == DP_F32) { KERNEL_CALL_F32; } else if ((dtype) == DP_BF16) { KERNEL_CALL_BF16; } \
+// runs CALL with the storage type bound to T (float | uint16_t = bf16 bits | _Float16)
+#define DISPATCH_DTYPE(dtype, ...)                                                  \
+  if ((dtype) == DP_F32) { using T = float; __VA_ARGS__; }                          \
+  else if ((dtype) == DP_BF16) { using T = uint16_t; __VA_ARGS__; }                 \
+  else if ((dtype) == DP_F16) { using T = f16_t; __VA_ARGS__; }                     \
   else return dp_fail(DP_ERR_BAD_ARG, "bad dtype %d", (int)(dtype));
 
 extern "C" int dp_preprocess_u8(const dp_preprocess_params* p, dp_stream_t stream) {
@@ -311,9 +314,7 @@ extern "C" int dp_preprocess_u8(const dp_preprocess_params* p, dp_stream_t strea
   const long long total = (long long)p->n_img * p->Hp * p->Wp;
   hipStream_t s = as_stream(stream);
   DISPATCH_DTYPE(p->dtype,
-                 hipLaunchKernelGGL(preprocess_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, p->src, (float*)p->dst,
-                                    p->n_img, p->h, p->w, p->Hp, p->Wp, p->mean[0], p->mean[1], p->mean[2], p->std[0], p->std[1], p->std[2]),
-                 hipLaunchKernelGGL(preprocess_kernel<uint16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, p->src, (uint16_t*)p->dst,
+                 hipLaunchKernelGGL(preprocess_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, p->src, (T*)p->dst,
                                     p->n_img, p->h, p->w, p->Hp, p->Wp, p->mean[0], p->mean[1], p->mean[2], p->std[0], p->std[1], p->std[2]));
   return dp_check_launch("preprocess_kernel");
 }
@@ -324,8 +325,7 @@ extern "C" int dp_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int
   const long long total = (long long)N * Ho * Wo * (C / 4);
   hipStream_t s = as_stream(stream);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(maxpool3x3s2_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const float*)in, (float*)out, N, H, W, C, Ho, Wo),
-                 hipLaunchKernelGGL(maxpool3x3s2_kernel<uint16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const uint16_t*)in, (uint16_t*)out, N, H, W, C, Ho, Wo));
+                 hipLaunchKernelGGL(maxpool3x3s2_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const T*)in, (T*)out, N, H, W, C, Ho, Wo));
   return dp_check_launch("maxpool3x3s2_kernel");
 }
 
@@ -335,8 +335,7 @@ extern "C" int dp_subsample2_nhwc(const void* in, void* out, int N, int H, int W
   const long long total = (long long)N * Ho * Wo * (C / 4);
   hipStream_t s = as_stream(stream);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(subsample2_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const float*)in, (float*)out, N, H, W, C, Ho, Wo),
-                 hipLaunchKernelGGL(subsample2_kernel<uint16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const uint16_t*)in, (uint16_t*)out, N, H, W, C, Ho, Wo));
+                 hipLaunchKernelGGL(subsample2_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const T*)in, (T*)out, N, H, W, C, Ho, Wo));
   return dp_check_launch("subsample2_kernel");
 }
 
@@ -346,8 +345,7 @@ extern "C" int dp_upsample_bilinear2x_nhwc(const void* in, void* out, int N, int
   const long long total = (long long)N * 4 * H * W * (C / 4);
   hipStream_t s = as_stream(stream);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const float*)in, (float*)out, N, H, W, C, accumulate),
-                 hipLaunchKernelGGL(upsample2x_kernel<uint16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const uint16_t*)in, (uint16_t*)out, N, H, W, C, accumulate));
+                 hipLaunchKernelGGL(upsample2x_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const T*)in, (T*)out, N, H, W, C, accumulate));
   return dp_check_launch("upsample2x_kernel");
 }
 
@@ -356,8 +354,7 @@ extern "C" int dp_add_nhwc(const void* in, void* out, int64_t count, int dtype, 
   if (count == 0) return DP_OK;
   hipStream_t s = as_stream(stream);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(count / 4)), dim3(kBlock), 0, s, (const float*)in, (float*)out, (long long)count / 4),
-                 hipLaunchKernelGGL(add_kernel<uint16_t>, dim3(grid_for(count / 4)), dim3(kBlock), 0, s, (const uint16_t*)in, (uint16_t*)out, (long long)count / 4));
+                 hipLaunchKernelGGL(add_kernel<T>, dim3(grid_for(count / 4)), dim3(kBlock), 0, s, (const T*)in, (T*)out, (long long)count / 4));
   return dp_check_launch("add_kernel");
 }
 
@@ -366,11 +363,21 @@ extern "C" int dp_cast(const void* in, int in_dtype, void* out, int out_dtype, i
   if (count == 0) return DP_OK;
   hipStream_t s = as_stream(stream);
   const dim3 g(grid_for(count)), b(kBlock);
-  if (in_dtype == DP_F32 && out_dtype == DP_BF16) hipLaunchKernelGGL((cast_kernel<float, uint16_t>), g, b, 0, s, (const float*)in, (uint16_t*)out, (long long)count);
-  else if (in_dtype == DP_BF16 && out_dtype == DP_F32) hipLaunchKernelGGL((cast_kernel<uint16_t, float>), g, b, 0, s, (const uint16_t*)in, (float*)out, (long long)count);
-  else if (in_dtype == DP_F32 && out_dtype == DP_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)in, (float*)out, (long long)count);
-  else if (in_dtype == DP_BF16 && out_dtype == DP_BF16) hipLaunchKernelGGL((cast_kernel<uint16_t, uint16_t>), g, b, 0, s, (const uint16_t*)in, (uint16_t*)out, (long long)count);
-  else return dp_fail(DP_ERR_BAD_ARG, "dp_cast: bad dtypes %d -> %d", in_dtype, out_dtype);
+#define DP_CAST_CASE(DI, TI, DO, TO)                                                                                     \
+  if (in_dtype == DI && out_dtype == DO)                                                                                 \
+    hipLaunchKernelGGL((cast_kernel<TI, TO>), g, b, 0, s, (const TI*)in, (TO*)out, (long long)count);                    \
+  else
+  DP_CAST_CASE(DP_F32, float, DP_F32, float)
+  DP_CAST_CASE(DP_F32, float, DP_BF16, uint16_t)
+  DP_CAST_CASE(DP_F32, float, DP_F16, f16_t)
+  DP_CAST_CASE(DP_BF16, uint16_t, DP_F32, float)
+  DP_CAST_CASE(DP_BF16, uint16_t, DP_BF16, uint16_t)
+  DP_CAST_CASE(DP_BF16, uint16_t, DP_F16, f16_t)
+  DP_CAST_CASE(DP_F16, f16_t, DP_F32, float)
+  DP_CAST_CASE(DP_F16, f16_t, DP_BF16, uint16_t)
+  DP_CAST_CASE(DP_F16, f16_t, DP_F16, f16_t)
+    return dp_fail(DP_ERR_BAD_ARG, "dp_cast: bad dtypes %d -> %d", in_dtype, out_dtype);
+#undef DP_CAST_CASE
   return dp_check_launch("cast_kernel");
 }
 
@@ -399,8 +406,7 @@ extern "C" int dp_merge_upsample2x_nhwc(const void* base, const void* const* ups
   const long long total = (long long)N * 4 * H * W * (C / 4);
   hipStream_t s = as_stream(stream);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(merge_up2x_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const float*)base, (const float*)u0, (const float*)u1, (const float*)u2, n_ups, (float*)out, N, H, W, C),
-                 hipLaunchKernelGGL(merge_up2x_kernel<uint16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const uint16_t*)base, (const uint16_t*)u0, (const uint16_t*)u1, (const uint16_t*)u2, n_ups, (uint16_t*)out, N, H, W, C));
+                 hipLaunchKernelGGL(merge_up2x_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const T*)base, (const T*)u0, (const T*)u1, (const T*)u2, n_ups, (T*)out, N, H, W, C));
   return dp_check_launch("merge_up2x_kernel");
 }
 
@@ -413,8 +419,7 @@ extern "C" int dp_groupnorm_relu_nhwc(const dp_groupnorm_params* p, dp_stream_t 
   hipStream_t s = as_stream(stream);
   const dim3 g(p->R * p->groups), b(kBlock);
   DISPATCH_DTYPE(p->dtype,
-                 hipLaunchKernelGGL(groupnorm_kernel<float>, g, b, 0, s, (float*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu),
-                 hipLaunchKernelGGL(groupnorm_kernel<uint16_t>, g, b, 0, s, (uint16_t*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu));
+                 hipLaunchKernelGGL(groupnorm_kernel<T>, g, b, 0, s, (T*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu));
   return dp_check_launch("groupnorm_kernel");
 }
 
@@ -423,8 +428,7 @@ extern "C" int dp_global_avgpool_nhwc(const void* in, void* out, int R, int HW, 
   DP_REQUIRE(in && out && R > 0 && HW > 0 && C > 0, "dp_global_avgpool_nhwc: bad args");
   hipStream_t s = as_stream(stream);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(gap_kernel<float>, dim3(R), dim3(kBlock), 0, s, (const float*)in, (float*)out, HW, C),
-                 hipLaunchKernelGGL(gap_kernel<uint16_t>, dim3(R), dim3(kBlock), 0, s, (const uint16_t*)in, (uint16_t*)out, HW, C));
+                 hipLaunchKernelGGL(gap_kernel<T>, dim3(R), dim3(kBlock), 0, s, (const T*)in, (T*)out, HW, C));
   return dp_check_launch("gap_kernel");
 }
 
@@ -436,7 +440,6 @@ extern "C" int dp_broadcast_hw_nhwc(const void* in, void* out, int R, int HW, in
   const long long total = (long long)R * HW * (C / 4);
   hipStream_t s = as_stream(stream);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(broadcast_hw_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const float*)in, (float*)out, R, HW, C, out_c_stride, out_c_off),
-                 hipLaunchKernelGGL(broadcast_hw_kernel<uint16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const uint16_t*)in, (uint16_t*)out, R, HW, C, out_c_stride, out_c_off));
+                 hipLaunchKernelGGL(broadcast_hw_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const T*)in, (T*)out, R, HW, C, out_c_stride, out_c_off));
   return dp_check_launch("broadcast_hw_kernel");
 }

@@ -38,8 +38,10 @@ class Engine:
         self.lib = L.load()
         self.cfg = cfg
         self.device = torch.device(device)
-        self.dt = L.DP_BF16 if dtype in ("bf16", "bfloat16") else L.DP_F32
-        self.tdt = torch.bfloat16 if self.dt == L.DP_BF16 else torch.float32
+        if dtype not in L.DTYPES:
+            raise ValueError("dtype must be one of %s" % sorted(L.DTYPES))
+        self.dt = L.DTYPES[dtype]
+        self.tdt = {L.DP_F32: torch.float32, L.DP_BF16: torch.bfloat16, L.DP_F16: torch.float16}[self.dt]
         self.model = PackedModel(cfg, state, self.dt, self.device)
         self.cell_anchors = []
         for size in cfg.anchor_sizes:  # anchor_generator.py:181-216 (python float64, then fp32)
@@ -111,7 +113,10 @@ class Engine:
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
             e1.record()
             cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_ring_kernel<256x256>", "conv_ring_kernel<128x128>", "conv_ring2_kernel<256x128>")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
-            self.prof.append((cls, flops, e0, e1, layer.name))
+            es = x.t.element_size()
+            nbytes = (N * (H * W if s == 1 else Ho * Wo * min(layer.ntaps, s * s)) * x.C * es + layer.weight.numel() * es
+                      + N * Ho * Wo * layer.cout * (es_out + (es if residual is not None else 0) // (4 if rshift else 1)))
+            self.prof.append((cls, flops, e0, e1, "%s %dx%dx%d->%d t%d" % (layer.name, Ho, Wo, x.C, layer.cout, layer.ntaps), nbytes))
         else:
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
         self.flops_last += flops

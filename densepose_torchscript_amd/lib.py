@@ -10,7 +10,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdensepose_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-DP_F32, DP_BF16 = 0, 1
+DP_F32, DP_BF16, DP_F16 = 0, 1, 2
+
+# user-facing dtype names -> (enum, element size)
+DTYPES = {"fp32": DP_F32, "float32": DP_F32, "bf16": DP_BF16, "bfloat16": DP_BF16, "fp16": DP_F16, "float16": DP_F16, "half": DP_F16}
 
 c_void_p, c_int, c_i32, c_i64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_float
 

@@ -10,7 +10,7 @@
 import numpy as np
 import torch
 
-from .lib import DP_BF16, DP_F32
+from .lib import DP_BF16, DP_F16, DP_F32
 from .weights import decoder_layout, resnet_blocks
 
 BN_EPS = 1e-5
@@ -20,6 +20,21 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
+def _cout_row_perm():
+    """Row order of the weight matrix inside every 64-cout block (dp_conv.hip store_tile): physical row i*16 + q*4 + e - row
+    q*4+e of the i-th 16x16 MFMA tile a wave owns along cout - carries logical cout (i>>1)*32 + q*8 + (i&1)*4 + e, so that the
+    accumulator registers of one lane are two runs of 8 consecutive output channels (16-byte stores straight from registers)."""
+    perm = np.zeros(64, dtype=np.int64)
+    for i in range(4):
+        for q in range(4):
+            for e in range(4):
+                perm[i * 16 + q * 4 + e] = (i >> 1) * 32 + q * 8 + (i & 1) * 4 + e
+    return perm
+
+
+COUT_ROW_PERM = _cout_row_perm()
+
+
 class PackedConv:
     """One dp_conv2d_nhwc layer resident on the device."""
 
@@ -27,7 +42,7 @@ class PackedConv:
         # wmat: float32 [Cout, ntaps, Cin] ; taps: list of (dy, dx)
         self.name = name
         self.dtype = dtype
-        es = 2 if dtype == DP_BF16 else 4
+        es = 4 if dtype == DP_F32 else 2
         ch = 16 // es
         co, nt, ci = wmat.shape
         assert nt == len(taps) and ci <= cin_alloc and cin_alloc % 8 == 0
@@ -49,9 +64,12 @@ class PackedConv:
             full = full.reshape(self.cout_w, nt, ncb, pe).transpose(0, 2, 1, 3)  # [co, cblock, tap, pe]
         flat = np.zeros((self.cout_w, self.kpad), dtype=np.float32)
         flat[:, :k] = full.reshape(self.cout_w, k)
+        flat = flat[COUT_ROW_PERM[None, :] + 64 * np.arange(self.cout_w // 64)[:, None]].reshape(self.cout_w, self.kpad)
         t = torch.from_numpy(flat)
         if dtype == DP_BF16:
             t = t.to(torch.bfloat16)
+        elif dtype == DP_F16:
+            t = t.to(torch.float16)  # the reference's .half() (export.py:36-37), applied to the BN-folded weights
         self.weight = t.to(device).contiguous()
         nchunk = self.kpad // ch
         ktab = np.zeros((nchunk, 4), dtype=np.int32)

@@ -12,7 +12,9 @@
  *     given hipStream_t and returns immediately: 0 = ok, <0 = dp_status error (nothing launched).
  *   - functions never allocate; workspaces are caller-provided.
  *   - activations are NHWC ("pixels x channels"), channel count padded to a multiple of 8;
- *     dtype is DP_F32 (parity mode, exact fp32 MFMA) or DP_BF16 (throughput mode, fp32 accumulate).
+ *     dtype is DP_F32 (parity mode, exact fp32 MFMA), DP_BF16 (throughput mode, fp32 accumulate) or DP_F16
+ *     (IEEE half storage + fp32 accumulate: the reference's `.half()` export, /root/reference/export.py:36-37,
+ *     run.py:26, with everything that is not a GEMM operand kept in fp32).
  *   - boxes, scores, anchors, decode, IoU, softmax are always fp32.
  */
 #ifndef DENSEPOSE_HIP_H
@@ -26,7 +28,7 @@ extern "C" {
 
 typedef void* dp_stream_t; /* hipStream_t */
 
-enum dp_dtype { DP_F32 = 0, DP_BF16 = 1 };
+enum dp_dtype { DP_F32 = 0, DP_BF16 = 1, DP_F16 = 2 };
 
 enum dp_status {
   DP_OK = 0,

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("input")
     ap.add_argument("--out", default="densepose_out.npz")
     ap.add_argument("--fp32", action="store_true", help="parity mode (exact fp32 MFMA) instead of bf16")
+    ap.add_argument("--fp16", action="store_true", help="IEEE half operands (the reference's export.py --fp16 / run.py default on GPU)")
     ap.add_argument("--min_score", type=float, default=0.3)
     args = ap.parse_args()
     from densepose_torchscript_amd import get_config, make_synthetic_state
@@ -38,7 +39,7 @@ def main():
     weights = args.weights
     if weights.startswith("synthetic"):
         weights = make_synthetic_state(cfg, int(weights.split(":")[1]) if ":" in weights else 0)
-    predictor = DensePosePredictor(cfg, weights, dtype="fp32" if args.fp32 else "bf16")
+    predictor = DensePosePredictor(cfg, weights, dtype="fp32" if args.fp32 else "fp16" if args.fp16 else "bf16")
     img = load_image(args.input)
     outputs = predictor(torch.from_numpy(img))
     results, xywh = extract_iuv(outputs)

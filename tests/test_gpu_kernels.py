@@ -14,7 +14,7 @@ def eng():
     from densepose_torchscript_amd import TINY_OPTS, get_config, make_synthetic_state
     from densepose_torchscript_amd.engine import Engine
     cfg = get_config("densepose_rcnn_R_50_FPN_s1x", TINY_OPTS)
-    return {dt: Engine(cfg, make_synthetic_state(cfg, 0), dtype=dt) for dt in ("fp32", "bf16")}
+    return {dt: Engine(cfg, make_synthetic_state(cfg, 0), dtype=dt) for dt in ("fp32", "bf16", "fp16")}
 
 
 def _nhwc(x, calloc, tdt, dev):
@@ -24,8 +24,9 @@ def _nhwc(x, calloc, tdt, dev):
     return t.to(tdt).to(dev)
 
 
-def _round_bf16(x):
-    return x.to(torch.bfloat16).to(torch.float32)
+def _round(x, dt):
+    """round to the storage type of mode `dt` (exactly representable operands -> only accumulation order differs)"""
+    return x.to({"bf16": torch.bfloat16, "fp16": torch.float16}[dt]).to(torch.float32)
 
 
 CONV_CASES = [
@@ -57,7 +58,7 @@ BIG_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("force", ["1", "2", "3"])   # 1: 256x256 ring kernel, 2: 128x128 ring kernel, 3: 256x128 two-WG ring kernel
 @pytest.mark.parametrize("case", BIG_CASES)
 def test_conv2d_ring_kernels(eng, dt, case, force, monkeypatch):
@@ -65,7 +66,7 @@ def test_conv2d_ring_kernels(eng, dt, case, force, monkeypatch):
     test_conv2d_matches_torch(eng, dt, case)
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_matches_torch(eng, dt, case):
     from densepose_torchscript_amd.engine import Act
@@ -76,14 +77,14 @@ def test_conv2d_matches_torch(eng, dt, case):
     x = torch.randn((N, Cin, H, W), generator=g)
     w = torch.randn((Cout, Cin, k, k), generator=g) * (1.0 / (Cin * k * k)) ** 0.5
     b = torch.randn((Cout,), generator=g)
-    if dt == "bf16":
-        x, w = _round_bf16(x), _round_bf16(w)
+    if dt != "fp32":
+        x, w = _round(x, dt), _round(w, dt)
     ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p, dilation=d)
     res = None
     if use_res:
         res = torch.randn(ref.shape, generator=g)
-        if dt == "bf16":
-            res = _round_bf16(res)
+        if dt != "fp32":
+            res = _round(res, dt)
         ref = ref + res.double()
     if relu:
         ref = F.relu(ref)
@@ -106,6 +107,15 @@ def test_conv2d_matches_torch(eng, dt, case):
     if layer.cout > Cout and not use_res:
         pad = out.t.cpu()[..., Cout:]
         assert float(pad.abs().max()) == 0.0
+    if dt != "fp32":
+        # storage-type output (what the layers of the model actually write): one rounding to bf16 / fp16 on top
+        out16 = e.conv(layer, xa, relu=relu, residual=ra)
+        torch.cuda.synchronize()
+        assert out16.t.dtype == e.tdt
+        got16 = out16.t.float().cpu()[..., :Cout].permute(0, 3, 1, 2).double()
+        ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+        bound = ulp * ref.abs() + tol * max(scale, 1.0) * (Cin * k * k) ** 0.5 + 1e-7
+        assert bool(((got16 - ref).abs() <= bound).all()), (case, float((got16 - ref).abs().max()))
 
 
 def test_conv_fpn_lateral_plus_nearest_upsample(eng):
@@ -152,13 +162,13 @@ def test_linear_and_deconv_forms(eng):
     assert torch.allclose(got, ref, atol=1e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 def test_pool_subsample_upsample(eng, dt):
     e = eng[dt]
     g = torch.Generator().manual_seed(5)
     x = torch.randn((2, 16, 13, 18), generator=g)
-    if dt == "bf16":
-        x = _round_bf16(x)
+    if dt != "fp32":
+        x = _round(x, dt)
     xa = _nhwc(x, 16, e.tdt, e.device)
     s = e._stream()
     out = torch.empty((2, 7, 9, 16), dtype=e.tdt, device=e.device)
@@ -211,7 +221,7 @@ def test_batched_nms_matches_oracle(eng, n_slots, groups):
         assert np.array_equal(os_[i, :cnt].cpu().numpy(), scores[i][keep])
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("multi", [True, False])
 def test_roi_align_matches_oracle(eng, dt, multi):
     from densepose_torchscript_amd.engine import Act
@@ -223,8 +233,8 @@ def test_roi_align_matches_oracle(eng, dt, multi):
     n_img, Cc = 2, 32
     shapes = [(40, 56), (20, 28), (10, 14), (5, 7)] if multi else [(40, 56)]
     maps = [torch.randn((n_img, Cc, h, w), generator=g) for h, w in shapes]
-    if dt == "bf16":
-        maps = [_round_bf16(m) for m in maps]
+    if dt != "fp32":
+        maps = [_round(m, dt) for m in maps]
     scales = [1.0 / 4, 1.0 / 8, 1.0 / 16, 1.0 / 32][: len(shapes)]
     max_rois, P = 50, 7
     boxes = np.stack([_random_boxes(rng, max_rois, 220.0, 0.1) for _ in range(n_img)])
