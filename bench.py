@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--streams", type=int, default=2, help="sub-batches of a step run concurrently on this many HIP streams")
+    ap.add_argument("--no-overlap", action="store_true", help="decoder in line instead of on a side stream")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-instrumented roofline pass (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,6 +100,10 @@ def main():
     if world > 1:
         parallel.broadcast_tensors(pred.engine.model.parameter_tensors(), src=0)
     eng = pred.engine
+    # `--streams 1 --no-graphs` is the fully serialized configuration (one kernel at a time on the chip) that profiles/ and
+    # the roofline pass use; otherwise the decoder also runs beside the RPN / box branch on a side stream
+    overlap = not (args.streams == 1 and args.no_graphs) and not args.no_overlap
+    eng.overlap_decoder = overlap
     hw = (args.height, args.width)
     frames = make_frames(args.batch, rank * args.batch, hw, device)  # weak scaling: every rank owns `batch` frames
     torch.cuda.synchronize()
@@ -142,7 +147,7 @@ def main():
         if rank == 0:
             print(json.dumps({"value": round(args.batch * world * args.steps / elapsed, 3), "ms_per_step": round(1e3 * elapsed / args.steps, 3)}), flush=True)
         return
-    pred.num_streams, eng.use_graphs = 1, False
+    pred.num_streams, eng.use_graphs, eng.overlap_decoder = 1, False, False
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -159,7 +164,7 @@ def main():
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
     eng.prof = None
-    pred.num_streams, eng.use_graphs = args.streams, not args.no_graphs
+    pred.num_streams, eng.use_graphs, eng.overlap_decoder = args.streams, not args.no_graphs, overlap
     dom = max(agg, key=lambda c: agg[c][1])
     dflops, dsec, dcalls = agg[dom]
     peak = PEAK_F32_MATRIX if args.dtype == "fp32" else PEAK_BF16_DENSE  # fp16 and bf16 MFMA share the dense peak

@@ -7,43 +7,70 @@
 namespace {
 
 // one separable pass of ATen's uint8 bilinear resize: out = clip((W0*x[i0] + W1*x[i1] + 2^(p-1)) >> p)
-__global__ void resize_h_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ tmp, int H, int W, int ow, int src_hwc,
-                                const int4* __restrict__ xtab, int prec) {
-  const long long total = 3ll * H * ow;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int xo = (int)(i % ow);
-    const long long t = i / ow;
-    const int y = (int)(t % H);
-    const int c = (int)(t / H);
-    const int4 e = xtab[xo];
-    int a, b;
-    if (src_hwc) {
-      a = src[((long long)y * W + e.x) * 3 + c];
-      b = src[((long long)y * W + e.y) * 3 + c];
-    } else {
-      a = src[((long long)c * H + y) * W + e.x];
-      b = src[((long long)c * H + y) * W + e.y];
-    }
-    int v = (e.z * a + e.w * b + (1 << (prec - 1))) >> prec;
-    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    tmp[i] = (uint8_t)v;
+// grid = (x blocks, 3*H rows, frames): no integer division; frames of one geometry are resized by ONE launch per pass
+constexpr int kMaxResizeBatch = 64;
+struct ResizeSrcs { const uint8_t* p[kMaxResizeBatch]; };
+
+// each thread produces 4 consecutive output bytes of a row (one 4-byte store when the row pitch allows it)
+__device__ __forceinline__ void put4(uint8_t* d, int xo, int ow, const int (&v)[4]) {
+  if (xo + 3 < ow && ((reinterpret_cast<uintptr_t>(d + xo) & 3) == 0)) {
+    *reinterpret_cast<uint32_t*>(d + xo) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (xo + k < ow) d[xo + k] = (uint8_t)v[k];
   }
+}
+
+__global__ void resize_h_kernel(const ResizeSrcs srcs, uint8_t* __restrict__ tmp, int H, int W, int ow, int src_hwc,
+                                const int4* __restrict__ xtab, int prec) {
+  const uint8_t* __restrict__ src = srcs.p[blockIdx.z];
+  uint8_t* __restrict__ timg = tmp + (long long)blockIdx.z * 3 * H * ow;
+  if (src_hwc) {
+    // interleaved source: one output column per thread, the three channels of its two taps are 3 adjacent bytes each
+    const int xo = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (xo >= ow || y >= H) return;
+    const int4 e = xtab[xo];
+    const uint8_t* __restrict__ pa = src + ((long long)y * W + e.x) * 3;
+    const uint8_t* __restrict__ pb = src + ((long long)y * W + e.y) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int r = (e.z * (int)pa[c] + e.w * (int)pb[c] + (1 << (prec - 1))) >> prec;
+      timg[((long long)c * H + y) * ow + xo] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+    return;
+  }
+  const int xo = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (xo >= ow) return;
+  const int row = blockIdx.y;          // c * H + y
+  const uint8_t* __restrict__ line = src + (long long)row * W;
+  int v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int4 e = xtab[xo + k < ow ? xo + k : ow - 1];
+    const int r = (e.z * (int)line[e.x] + e.w * (int)line[e.y] + (1 << (prec - 1))) >> prec;
+    v[k] = r < 0 ? 0 : (r > 255 ? 255 : r);
+  }
+  put4(timg + (long long)row * ow, xo, ow, v);
 }
 __global__ void resize_v_kernel(const uint8_t* __restrict__ tmp, uint8_t* __restrict__ dst, int H, int oh, int ow,
                                 const int4* __restrict__ ytab, int prec) {
-  const long long total = 3ll * oh * ow;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int xo = (int)(i % ow);
-    const long long t = i / ow;
-    const int yo = (int)(t % oh);
-    const int c = (int)(t / oh);
-    const int4 e = ytab[yo];
-    const int a = tmp[((long long)c * H + e.x) * ow + xo];
-    const int b = tmp[((long long)c * H + e.y) * ow + xo];
-    int v = (e.z * a + e.w * b + (1 << (prec - 1))) >> prec;
-    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    dst[i] = (uint8_t)v;
+  const int xo = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (xo >= ow) return;
+  const int row = blockIdx.y;          // c * oh + yo
+  const int c = row / oh, yo = row - c * oh;
+  const int4 e = ytab[yo];
+  const uint8_t* __restrict__ t = tmp + ((long long)blockIdx.z * 3 + c) * H * ow;
+  const uint8_t* __restrict__ la = t + (long long)e.x * ow;
+  const uint8_t* __restrict__ lb = t + (long long)e.y * ow;
+  int v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int x = xo + k < ow ? xo + k : ow - 1;
+    const int r = (e.z * (int)la[x] + e.w * (int)lb[x] + (1 << (prec - 1))) >> prec;
+    v[k] = r < 0 ? 0 : (r > 255 ? 255 : r);
   }
+  put4(dst + ((long long)blockIdx.z * 3 * oh + row) * ow, xo, ow, v);
 }
 
 __device__ __forceinline__ void src_index(int o, float scale, int n, int& i0, int& i1, float& l) {
@@ -101,20 +128,45 @@ __global__ void iuv_extract_kernel(const dp_iuv_extract_params p) {
 
 }  // namespace
 
-extern "C" int dp_resize_u8_bilinear(const dp_resize_params* p, dp_stream_t stream) {
-  DP_REQUIRE(p && p->src && p->tmp && p->dst && p->xtab && p->ytab, "dp_resize_u8_bilinear: null pointer");
+static int resize_launch(const dp_resize_params* p, const void* const* srcs, int n, hipStream_t s) {
+  DP_REQUIRE(3ll * p->H < 65536 && 3ll * p->oh < 65536, "dp_resize_u8_bilinear: more than 21845 rows");
+  for (int first = 0; first < n; first += kMaxResizeBatch) {
+    const int cnt = n - first < kMaxResizeBatch ? n - first : kMaxResizeBatch;
+    ResizeSrcs a;
+    for (int i = 0; i < cnt; ++i) {
+      DP_REQUIRE(srcs[first + i], "dp_resize_u8_bilinear: null frame %d", first + i);
+      a.p[i] = static_cast<const uint8_t*>(srcs[first + i]);
+    }
+    uint8_t* tmp = p->tmp + (long long)first * 3 * p->H * p->ow;
+    uint8_t* dst = p->dst + (long long)first * 3 * p->oh * p->ow;
+    const int gx = (p->ow + 4 * 256 - 1) / (4 * 256);   // 4 output bytes per thread
+    const dim3 gh = p->src_hwc ? dim3((p->ow + 255) / 256, p->H, cnt) : dim3(gx, 3 * p->H, cnt);
+    hipLaunchKernelGGL(resize_h_kernel, gh, dim3(256), 0, s, a, tmp, p->H, p->W, p->ow, p->src_hwc,
+                       reinterpret_cast<const int4*>(p->xtab), p->xprec);
+    hipLaunchKernelGGL(resize_v_kernel, dim3(gx, 3 * p->oh, cnt), dim3(256), 0, s, tmp, dst, p->H, p->oh, p->ow,
+                       reinterpret_cast<const int4*>(p->ytab), p->yprec);
+  }
+  return dp_check_launch("resize kernels");
+}
+
+static int resize_check(const dp_resize_params* p) {
+  DP_REQUIRE(p && p->tmp && p->dst && p->xtab && p->ytab, "dp_resize_u8_bilinear: null pointer");
   DP_REQUIRE(p->H > 0 && p->W > 0 && p->oh > 0 && p->ow > 0, "dp_resize_u8_bilinear: bad shape");
   DP_REQUIRE(p->xprec > 0 && p->xprec < 23 && p->yprec > 0 && p->yprec < 23, "dp_resize_u8_bilinear: precision");
-  hipStream_t s = as_stream(stream);
-  long long t1 = 3ll * p->H * p->ow, t2 = 3ll * p->oh * p->ow;
-  int g1 = (int)((t1 + 255) / 256), g2 = (int)((t2 + 255) / 256);
-  if (g1 > 4096) g1 = 4096;
-  if (g2 > 4096) g2 = 4096;
-  hipLaunchKernelGGL(resize_h_kernel, dim3(g1), dim3(256), 0, s, p->src, p->tmp, p->H, p->W, p->ow, p->src_hwc,
-                     reinterpret_cast<const int4*>(p->xtab), p->xprec);
-  hipLaunchKernelGGL(resize_v_kernel, dim3(g2), dim3(256), 0, s, p->tmp, p->dst, p->H, p->oh, p->ow,
-                     reinterpret_cast<const int4*>(p->ytab), p->yprec);
-  return dp_check_launch("resize kernels");
+  return DP_OK;
+}
+
+extern "C" int dp_resize_u8_bilinear(const dp_resize_params* p, dp_stream_t stream) {
+  if (int rc = resize_check(p)) return rc;
+  const void* src = p->src;
+  return resize_launch(p, &src, 1, as_stream(stream));
+}
+
+extern "C" int dp_resize_u8_bilinear_batch(const dp_resize_params* p, const void* const* srcs, int n, dp_stream_t stream) {
+  if (int rc = resize_check(p)) return rc;
+  DP_REQUIRE(srcs && n >= 0, "dp_resize_u8_bilinear_batch: bad frame list");
+  if (n == 0) return DP_OK;
+  return resize_launch(p, srcs, n, as_stream(stream));
 }
 
 extern "C" int dp_iuv_extract(const dp_iuv_extract_params* p, dp_stream_t stream) {

@@ -43,18 +43,21 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ src, T* __restrict
 }
 
 // ---- 3x3 stride-2 pad-1 max pool -------------------------------------------------------------------
+// one workgroup per output row: 32-bit index math, 16-byte (8-channel) accesses
 template <typename T>
-__global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C, int Ho, int Wo) {
-  const int C4 = C >> 2;
-  const long long total = (long long)N * Ho * Wo * C4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    long long t = i / C4;
-    const int wo = (int)(t % Wo);
-    t /= Wo;
-    const int ho = (int)(t % Ho);
-    const int n = (int)(t / Ho);
-    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+__global__ __launch_bounds__(kBlock) void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C, int Ho,
+                                                              int Wo) {
+  const int C8 = C >> 3;
+  const int row = blockIdx.x;  // n * Ho + ho
+  const int n = row / Ho, ho = row - n * Ho;
+  const T* img = in + (long long)n * H * W * C;
+  T* orow = out + (long long)row * Wo * C;
+  const int items = Wo * C8;
+  for (int i = threadIdx.x; i < items; i += kBlock) {
+    const int wo = i / C8, c = (i - wo * C8) * 8;
+    float m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       const int y = ho * 2 - 1 + dy;
@@ -63,11 +66,13 @@ __global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ ou
       for (int dx = 0; dx < 3; ++dx) {
         const int x = wo * 2 - 1 + dx;
         if ((unsigned)x >= (unsigned)W) continue;
-        const float4 v = load4(in + (((long long)n * H + y) * W + x) * C + c4 * 4);
-        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        float v[8];
+        load8(img + ((long long)y * W + x) * C + c, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], v[k]);
       }
     }
-    store4(out + i * 4, m);
+    store8(orow + wo * C + c, m);
   }
 }
 
@@ -96,43 +101,45 @@ __device__ __forceinline__ void bil_src(int o, int n, int& i0, int& i1, float& l
   i1 = i0 + (i0 < n - 1 ? 1 : 0);
   l = s - (float)i0;
 }
-__device__ __forceinline__ float4 lerp2d(float4 a, float4 b, float4 c, float4 d, float lx, float ly) {
+__device__ __forceinline__ float lerp2d1(float a, float b, float c, float d, float lx, float ly) {
   // ATen order: h0lambda * (w0lambda * p00 + w1lambda * p01) + h1lambda * (w0lambda * p10 + w1lambda * p11)
   const float hx = 1.f - lx, hy = 1.f - ly;
-  float4 r;
-  r.x = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
-  r.y = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
-  r.z = hy * (hx * a.z + lx * b.z) + ly * (hx * c.z + lx * d.z);
-  r.w = hy * (hx * a.w + lx * b.w) + ly * (hx * c.w + lx * d.w);
-  return r;
+  return hy * (hx * a + lx * b) + ly * (hx * c + lx * d);
 }
 
+// one workgroup per output row (n, yo): the vertical taps are uniform, 32-bit index math, 16-byte accesses
 template <typename T>
-__global__ void upsample2x_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C, int accumulate) {
-  const int C4 = C >> 2, Ho = 2 * H, Wo = 2 * W;
-  const long long total = (long long)N * Ho * Wo * C4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    long long t = i / C4;
-    const int xo = (int)(t % Wo);
-    t /= Wo;
-    const int yo = (int)(t % Ho);
-    const int n = (int)(t / Ho);
-    int y0, y1, x0, x1;
-    float ly, lx;
-    bil_src(yo, H, y0, y1, ly);
+__global__ __launch_bounds__(kBlock) void upsample2x_kernel(const T* __restrict__ in, T* __restrict__ out, int N, int H, int W, int C,
+                                                            int accumulate) {
+  const int C8 = C >> 3, Ho = 2 * H, Wo = 2 * W;
+  const int row = blockIdx.x;
+  const int n = row / Ho, yo = row - n * Ho;
+  int y0, y1;
+  float ly;
+  bil_src(yo, H, y0, y1, ly);
+  const T* r0 = in + ((long long)n * H + y0) * W * C;
+  const T* r1 = in + ((long long)n * H + y1) * W * C;
+  T* orow = out + (long long)row * Wo * C;
+  const int items = Wo * C8;
+  for (int i = threadIdx.x; i < items; i += kBlock) {
+    const int xo = i / C8, c = (i - xo * C8) * 8;
+    int x0, x1;
+    float lx;
     bil_src(xo, W, x0, x1, lx);
-    const T* base = in + (long long)n * H * W * C + c4 * 4;
-    const float4 a = load4(base + ((long long)y0 * W + x0) * C);
-    const float4 b = load4(base + ((long long)y0 * W + x1) * C);
-    const float4 c = load4(base + ((long long)y1 * W + x0) * C);
-    const float4 d = load4(base + ((long long)y1 * W + x1) * C);
-    float4 r = lerp2d(a, b, c, d, lx, ly);
+    float a[8], b[8], cc[8], d[8], r[8];
+    load8(r0 + x0 * C + c, a);
+    load8(r0 + x1 * C + c, b);
+    load8(r1 + x0 * C + c, cc);
+    load8(r1 + x1 * C + c, d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = lerp2d1(a[k], b[k], cc[k], d[k], lx, ly);
     if (accumulate) {
-      const float4 o = load4(out + i * 4);
-      r.x = o.x + r.x; r.y = o.y + r.y; r.z = o.z + r.z; r.w = o.w + r.w;
+      float o[8];
+      load8(orow + xo * C + c, o);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r[k] = o[k] + r[k];
     }
-    store4(out + i * 4, r);
+    store8(orow + xo * C + c, r);
   }
 }
 
@@ -158,21 +165,36 @@ constexpr int kIuvMaxRowFloats = 56 * 96;  // Ws * in_c of the largest supported
 
 __global__ __launch_bounds__(256) void iuv_upsample_split_kernel(const float* __restrict__ in, int R, int Hs, int Ws, int in_c, int n_coarse,
                                                                  int n_fine, float* __restrict__ coarse, float* __restrict__ fine,
-                                                                 float* __restrict__ u, float* __restrict__ v) {
-  extern __shared__ __attribute__((aligned(16))) float rows[];  // [2][Ws * in_c]
+                                                                 float* __restrict__ u, float* __restrict__ v, int xslots) {
+  // LDS image: [2 rows][in_c][Ws + 1] - channel-major, so that the lanes of the interpolation loop (consecutive x of one
+  // channel) read consecutive words (pixel-major staging put them in_c words apart: in_c = 80 -> 8-way bank conflicts)
+  extern __shared__ __attribute__((aligned(16))) float rows[];
   const int r = blockIdx.y;
   const int i = (int)blockIdx.x - 1;            // source row pair (i, i+1), i in [-1, Hs-1]
   const int y0 = i < 0 ? 0 : i;
   const int y1 = i + 1 > Hs - 1 ? Hs - 1 : i + 1;
-  const int rowf = Ws * in_c;
+  const int rowf = Ws * in_c, pitch = Ws + 1, plane = in_c * pitch;
   const float* src = in + (long long)r * Hs * rowf;
   for (int t = threadIdx.x * 4; t < rowf; t += 256 * 4) {
-    *reinterpret_cast<float4*>(rows + t) = *reinterpret_cast<const float4*>(src + (long long)y0 * rowf + t);
-    *reinterpret_cast<float4*>(rows + rowf + t) = *reinterpret_cast<const float4*>(src + (long long)y1 * rowf + t);
+    const float4 a = *reinterpret_cast<const float4*>(src + (long long)y0 * rowf + t);
+    const float4 b = *reinterpret_cast<const float4*>(src + (long long)y1 * rowf + t);
+    const int x = t / in_c, c = t - x * in_c;   // in_c % 4 == 0: the four channels belong to one pixel
+    float* d = rows + c * pitch + x;
+    d[0] = a.x; d[pitch] = a.y; d[2 * pitch] = a.z; d[3 * pitch] = a.w;
+    d += plane;
+    d[0] = b.x; d[pitch] = b.y; d[2 * pitch] = b.z; d[3 * pitch] = b.w;
   }
   __syncthreads();
   const int Ho = 2 * Hs, Wo = 2 * Ws, Ctot = n_coarse + 3 * n_fine;
   const long long hw = (long long)Ho * Wo;
+  // thread = (x slot, channel lane): the horizontal taps are computed once per thread, the channel is wave-uniform (the
+  // x slots of a channel lane span whole waves), so the loop body is 4 LDS reads + the lerp + one coalesced store
+  const int xo = threadIdx.x & (xslots - 1), cl = threadIdx.x / xslots, n_cl = 256 / xslots;
+  if (xo >= Wo) return;
+  int x0, x1;
+  float lx;
+  bil_src(xo, Ws, x0, x1, lx);
+  const float hx = 1.f - lx;
   // output rows whose bilinear source rows are exactly (y0, y1): yo = 2i+1 (ly = .25) and 2i+2 (ly = .75);
   // the clamped border rows: yo = 0 <- pair i = -1 (y0 = y1 = 0, ly = 0), yo = Ho-1 <- pair i = Hs-1 (y0 = y1, ly irrelevant)
   for (int k = 0; k < 2; ++k) {
@@ -180,19 +202,13 @@ __global__ __launch_bounds__(256) void iuv_upsample_split_kernel(const float* __
     if (yo < 0 || yo >= Ho) continue;
     int yy0, yy1;
     float ly;
-    bil_src(yo, Hs, yy0, yy1, ly);
+    bil_src(yo, Hs, yy0, yy1, ly);   // rows[] holds (y0, y1) = (yy0, yy1) by construction
     const float hy = 1.f - ly;
-    for (int t = threadIdx.x; t < Ctot * Wo; t += 256) {
-      const int c = t / Wo, xo = t - c * Wo;
-      int x0, x1;
-      float lx;
-      bil_src(xo, Ws, x0, x1, lx);
-      const float hx = 1.f - lx;
-      const float a = rows[x0 * in_c + c], b = rows[x1 * in_c + c];
-      const float cc = rows[rowf + x0 * in_c + c], d = rows[rowf + x1 * in_c + c];
-      // rows[] holds (y0, y1) = (yy0, yy1) by construction
+    const long long pix = (long long)yo * Wo + xo;
+    for (int c = cl; c < Ctot; c += n_cl) {
+      const float* ra = rows + c * pitch;
+      const float a = ra[x0], b = ra[x1], cc = ra[plane + x0], d = ra[plane + x1];
       const float val = hy * (hx * a + lx * b) + ly * (hx * cc + lx * d);
-      const long long pix = (long long)yo * Wo + xo;
       if (c < n_coarse) coarse[((long long)r * n_coarse + c) * hw + pix] = val;
       else if (c < n_coarse + n_fine) fine[((long long)r * n_fine + (c - n_coarse)) * hw + pix] = val;
       else if (c < n_coarse + 2 * n_fine) u[((long long)r * n_fine + (c - n_coarse - n_fine)) * hw + pix] = val;
@@ -203,34 +219,67 @@ __global__ __launch_bounds__(256) void iuv_upsample_split_kernel(const float* __
 
 // ---- decoder level merge: out = base + sum_k bilinear_x2(ups[k]) in ONE pass (roi_head.py:71-79) -------------
 template <typename T>
-__global__ void merge_up2x_kernel(const T* __restrict__ base, const T* __restrict__ u0, const T* __restrict__ u1,
-                                  const T* __restrict__ u2, int n_ups, T* __restrict__ out, int N, int H, int W, int C) {
-  // H, W are the LOW-res dims of the ups; base/out are [N, 2H, 2W, C]
-  const int C4 = C >> 2, Ho = 2 * H, Wo = 2 * W;
-  const long long total = (long long)N * Ho * Wo * C4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    long long t = i / C4;
-    const int xo = (int)(t % Wo);
-    t /= Wo;
-    const int yo = (int)(t % Ho);
-    const int n = (int)(t / Ho);
-    int y0, y1, x0, x1;
-    float ly, lx;
-    bil_src(yo, H, y0, y1, ly);
-    bil_src(xo, W, x0, x1, lx);
-    float4 acc = load4(base + i * 4);
-    const long long o00 = (((long long)n * H + y0) * W + x0) * C + c4 * 4, o01 = (((long long)n * H + y0) * W + x1) * C + c4 * 4;
-    const long long o10 = (((long long)n * H + y1) * W + x0) * C + c4 * 4, o11 = (((long long)n * H + y1) * W + x1) * C + c4 * 4;
-    const T* ups[3] = {u0, u1, u2};
+__global__ __launch_bounds__(kBlock) void merge_up2x_kernel(const T* __restrict__ base, const T* __restrict__ u0, const T* __restrict__ u1,
+                                                            const T* __restrict__ u2, int n_ups, T* __restrict__ out, int N, int H, int W,
+                                                            int C) {
+  // H, W are the LOW-res dims of the ups; base/out are [N, 2H, 2W, C].
+  // One workgroup per output ROW PAIR (2p-1, 2p), p = 0..H, one thread per column pair (2q-1, 2q), q = 0..W, and 8
+  // channels: the four outputs of such a 2x2 block interpolate between the SAME four low-res samples (rows p-1, p and
+  // columns q-1, q), so each up map costs 4 loads per 4 outputs instead of 16. Taps and weights still come from bil_src
+  // per output row / column, so every output is computed by exactly the expression of the unblocked form.
+  const int C8 = C >> 3, Ho = 2 * H, Wo = 2 * W;
+  const int n = blockIdx.x / (H + 1), p = blockIdx.x - n * (H + 1);
+  const int ya = 2 * p - 1, yb = 2 * p;          // output rows of this pair (ya < 0 / yb >= Ho: absent)
+  const bool has_a = ya >= 0, has_b = yb < Ho;
+  int y0, y1, t0, t1;
+  float lya = 0.f, lyb = 0.f;
+  if (has_a) bil_src(ya, H, y0, y1, lya);
+  if (has_b) bil_src(yb, H, has_a ? t0 : y0, has_a ? t1 : y1, lyb);   // same taps as row ya when both exist
+  const long long o0 = ((long long)n * H + y0) * W * C, o1 = ((long long)n * H + y1) * W * C;
+  const long long ra = ((long long)n * Ho + ya) * Wo * C, rb = ((long long)n * Ho + yb) * Wo * C;
+  const T* ups[3] = {u0, u1, u2};
+  const int items = (W + 1) * C8;
+  for (int i = threadIdx.x; i < items; i += kBlock) {
+    const int q = i / C8, c = (i - q * C8) * 8;
+    const int xa = 2 * q - 1, xb = 2 * q;
+    const bool has_xa = xa >= 0, has_xb = xb < Wo;
+    int x0, x1, s0, s1;
+    float lxa = 0.f, lxb = 0.f;
+    if (has_xa) bil_src(xa, W, x0, x1, lxa);
+    if (has_xb) bil_src(xb, W, has_xa ? s0 : x0, has_xa ? s1 : x1, lxb);
+    float acc[2][2][8] = {};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (k < n_ups) {
-        const float4 r = lerp2d(load4(ups[k] + o00), load4(ups[k] + o01), load4(ups[k] + o10), load4(ups[k] + o11), lx, ly);
-        acc.x = acc.x + r.x; acc.y = acc.y + r.y; acc.z = acc.z + r.z; acc.w = acc.w + r.w;
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const bool ok = (r ? has_b : has_a) && (k ? has_xb : has_xa);
+        if (ok) load8(base + (r ? rb : ra) + (long long)(k ? xb : xa) * C + c, acc[r][k]);
+      }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      if (m < n_ups) {
+        float a[8], b[8], cc[8], d[8];
+        load8(ups[m] + o0 + x0 * C + c, a);
+        load8(ups[m] + o0 + x1 * C + c, b);
+        load8(ups[m] + o1 + x0 * C + c, cc);
+        load8(ups[m] + o1 + x1 * C + c, d);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float ly = r ? lyb : lya, lx = k ? lxb : lxa;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[r][k][e] = acc[r][k][e] + lerp2d1(a[e], b[e], cc[e], d[e], lx, ly);
+          }
       }
     }
-    store4(out + i * 4, acc);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const bool ok = (r ? has_b : has_a) && (k ? has_xb : has_xa);
+        if (ok) store8(out + (r ? rb : ra) + (long long)(k ? xb : xa) * C + c, acc[r][k]);
+      }
   }
 }
 
@@ -320,12 +369,12 @@ extern "C" int dp_preprocess_u8(const dp_preprocess_params* p, dp_stream_t strea
 }
 
 extern "C" int dp_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, dp_stream_t stream) {
-  DP_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dp_maxpool3x3s2_nhwc: bad args");
+  DP_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "dp_maxpool3x3s2_nhwc: bad args");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const long long total = (long long)N * Ho * Wo * (C / 4);
+  DP_REQUIRE((long long)H * W * C < (1ll << 31) && (long long)N * Ho < (1ll << 31), "dp_maxpool3x3s2_nhwc: image too large");
   hipStream_t s = as_stream(stream);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(maxpool3x3s2_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const T*)in, (T*)out, N, H, W, C, Ho, Wo));
+                 hipLaunchKernelGGL(maxpool3x3s2_kernel<T>, dim3(N * Ho), dim3(kBlock), 0, s, (const T*)in, (T*)out, N, H, W, C, Ho, Wo));
   return dp_check_launch("maxpool3x3s2_kernel");
 }
 
@@ -341,11 +390,11 @@ extern "C" int dp_subsample2_nhwc(const void* in, void* out, int N, int H, int W
 
 extern "C" int dp_upsample_bilinear2x_nhwc(const void* in, void* out, int N, int H, int W, int C, int accumulate, int dtype,
                                            dp_stream_t stream) {
-  DP_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dp_upsample_bilinear2x_nhwc: bad args");
-  const long long total = (long long)N * 4 * H * W * (C / 4);
+  DP_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "dp_upsample_bilinear2x_nhwc: bad args");
+  DP_REQUIRE(2ll * W * C < (1ll << 31) && 2ll * N * H < (1ll << 31), "dp_upsample_bilinear2x_nhwc: image too large");
   hipStream_t s = as_stream(stream);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(upsample2x_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const T*)in, (T*)out, N, H, W, C, accumulate));
+                 hipLaunchKernelGGL(upsample2x_kernel<T>, dim3(2 * N * H), dim3(kBlock), 0, s, (const T*)in, (T*)out, N, H, W, C, accumulate));
   return dp_check_launch("upsample2x_kernel");
 }
 
@@ -390,23 +439,26 @@ extern "C" int dp_iuv_upsample_split(const dp_iuv_params* p, dp_stream_t stream)
   DP_REQUIRE(p->in_c % 4 == 0 && p->Ws * p->in_c <= kIuvMaxRowFloats, "dp_iuv_upsample_split: row of %d x %d floats exceeds the LDS staging",
              p->Ws, p->in_c);
   DP_REQUIRE(p->R <= 65535, "dp_iuv_upsample_split: R too large");
-  const int lds = 2 * p->Ws * p->in_c * (int)sizeof(float);
+  const int lds = 2 * (p->Ws + 1) * p->in_c * (int)sizeof(float);
+  DP_REQUIRE(2 * p->Ws <= 256, "dp_iuv_upsample_split: output rows wider than 256");
+  int xslots = 64;   // power of two >= the output width: a channel lane covers whole waves
+  while (xslots < 2 * p->Ws) xslots *= 2;
   hipLaunchKernelGGL(iuv_upsample_split_kernel, dim3(p->Hs + 1, p->R), dim3(256), lds, as_stream(stream), p->in, p->R, p->Hs, p->Ws,
-                     p->in_c, p->n_coarse, p->n_fine, p->coarse, p->fine, p->u, p->v);
+                     p->in_c, p->n_coarse, p->n_fine, p->coarse, p->fine, p->u, p->v, xslots);
   return dp_check_launch("iuv_upsample_split_kernel");
 }
 
 extern "C" int dp_merge_upsample2x_nhwc(const void* base, const void* const* ups, int n_ups, void* out, int N, int H, int W, int C,
                                         int dtype, dp_stream_t stream) {
-  DP_REQUIRE(base && ups && out && n_ups >= 1 && n_ups <= 3 && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dp_merge_upsample2x_nhwc: bad args");
+  DP_REQUIRE(base && ups && out && n_ups >= 1 && n_ups <= 3 && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "dp_merge_upsample2x_nhwc: bad args");
+  DP_REQUIRE(2ll * W * C < (1ll << 31) && 2ll * N * H < (1ll << 31), "dp_merge_upsample2x_nhwc: image too large");
   for (int k = 0; k < n_ups; ++k) DP_REQUIRE(ups[k], "dp_merge_upsample2x_nhwc: null map %d", k);
   const void* u0 = ups[0];
   const void* u1 = n_ups > 1 ? ups[1] : nullptr;
   const void* u2 = n_ups > 2 ? ups[2] : nullptr;
-  const long long total = (long long)N * 4 * H * W * (C / 4);
   hipStream_t s = as_stream(stream);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(merge_up2x_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const T*)base, (const T*)u0, (const T*)u1, (const T*)u2, n_ups, (T*)out, N, H, W, C));
+                 hipLaunchKernelGGL(merge_up2x_kernel<T>, dim3(N * (H + 1)), dim3(kBlock), 0, s, (const T*)base, (const T*)u0, (const T*)u1, (const T*)u2, n_ups, (T*)out, N, H, W, C));
   return dp_check_launch("merge_up2x_kernel");
 }
 

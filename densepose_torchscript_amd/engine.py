@@ -57,6 +57,8 @@ class Engine:
         self.flops_last = 0
         self.prof = None  # list of (kernel class, algorithmic flops, start event, end event) when profiling
         self.use_graphs = False
+        self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
+        self._side_streams = {}
         self._graphs = {}
         self._pinned = {}
 
@@ -346,7 +348,7 @@ class Engine:
         L.check(self.lib.dp_iuv_upsample_split(C.byref(p), self._stream()), "dp_iuv_upsample_split")
         return coarse, fine, u, v
 
-    def densepose_branch(self, feats, det_boxes, det_counts_dev, counts_host):
+    def densepose_branch(self, feats, det_boxes, det_counts_dev, counts_host, dec=None):
         cfg = self.cfg
         n = feats["p2"].N
         D = det_boxes.shape[1]
@@ -355,7 +357,7 @@ class Engine:
         offs[1:] = np.cumsum(counts_host)[:-1]
         offsets = torch.from_numpy(offs).to(self.device, non_blocking=True)
         if cfg.dp_decoder_on:
-            dec = self.decoder(feats)
+            dec = dec if dec is not None else self.decoder(feats)
             maps, scales = [dec], [1.0 / 4]
             if self.keep_intermediates:
                 self.inter["decoder_out"] = dec
@@ -390,6 +392,17 @@ class Engine:
         feats = self.backbone(x)
         if self.keep_intermediates:
             self.inter.update(feats)
+        # The decoder (roi_head.py:42-79) reads only the FPN maps, not the detections: it runs on a side stream beside the
+        # RPN / box branch, whose top-k, NMS and small-M GEMM launches cannot fill the chip on their own.
+        dec, side = None, None
+        if self.cfg.dp_decoder_on and self.overlap_decoder:
+            cur = torch.cuda.current_stream(self.device)
+            side = self._side_streams.get(cur.cuda_stream)
+            if side is None:
+                side = self._side_streams[cur.cuda_stream] = torch.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                dec = self.decoder(feats)
         if given_boxes is None:
             props, prop_scores, prop_counts = self.rpn(feats, Hp, Wp)
             if self.keep_intermediates:
@@ -397,7 +410,10 @@ class Engine:
             det_boxes, det_scores, det_counts = self.box_branch(feats, props, prop_counts)
         else:
             det_boxes, det_scores, det_counts = given_boxes
-        return dict(n=n, h=h, w=w, feats=feats, det_boxes=det_boxes, det_scores=det_scores, det_counts=det_counts)
+        if side is not None:
+            cur.wait_stream(side)
+            dec.t.record_stream(cur)
+        return dict(n=n, h=h, w=w, feats=feats, det_boxes=det_boxes, det_scores=det_scores, det_counts=det_counts, dec=dec)
 
     def _pinned_counts(self, key, n):
         buf = self._pinned.get(key)
@@ -448,7 +464,7 @@ class Engine:
         det_boxes, det_scores, det_counts = st["det_boxes"], st["det_scores"], st["det_counts"]
         st["counts_event"].synchronize()
         counts_host = st["counts_pinned"].numpy().astype(np.int64)
-        coarse, fine, u, v, offs = self.densepose_branch(st["feats"], det_boxes, det_counts, counts_host)
+        coarse, fine, u, v, offs = self.densepose_branch(st["feats"], det_boxes, det_counts, counts_host, st.get("dec"))
         # detector_postprocess (postprocessing.py:43-54); image_size there is [W_pad, H_pad] (Q1) minus the padding
         D = det_boxes.shape[1]
         meta = np.zeros((n, 4), dtype=np.float32)

@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdensepose_hip.so")
+LIB_PATH = os.environ.get("DP_HIP_LIB") or os.path.join(_HERE, "libdensepose_hip.so")  # DP_HIP_LIB: A/B builds (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 
 DP_F32, DP_BF16, DP_F16 = 0, 1, 2
@@ -123,6 +123,7 @@ SYMBOLS = {
     "dp_broadcast_hw_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_i64, c_void_p]),
     "dp_resize_u8_bilinear": (c_int, [C.POINTER(ResizeParams), c_void_p]),
+    "dp_resize_u8_bilinear_batch": (c_int, [C.POINTER(ResizeParams), C.POINTER(c_void_p), c_int, c_void_p]),
     "dp_iuv_extract": (c_int, [C.POINTER(IuvExtractParams), c_void_p]),
 }
 

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from .config import ModelConfig, get_config
 from .engine import Engine
-from .resize import resize_u8_device
+from .resize import resize_u8_device_batch
 from .weights import check_state, load_checkpoint
 
 
@@ -57,15 +57,17 @@ class DensePosePredictor:
     def _scale(self, height, width):
         return min(self.min_size / min(height, width), self.max_size / max(height, width))
 
-    def _resize(self, chw):
-        height, width = int(chw.shape[1]), int(chw.shape[2])
+    def _resize_group(self, chws):
+        """chws: CHW views of ONE geometry -> uint8 [n,3,oh,ow] on the device (defaults.py:89, once per frame there)."""
+        height, width = int(chws[0].shape[1]), int(chws[0].shape[2])
         k = self._scale(height, width)
         if self.resize_mode == "device":
-            if chw.stride(0) == 1 and chw.stride(2) == 3:  # permuted view of a contiguous HWC frame: resize straight from HWC
-                return resize_u8_device(self.engine, chw.permute(1, 2, 0).to(self.device), k, src_hwc=True)
-            return resize_u8_device(self.engine, chw.to(self.device), k)
-        image = F.interpolate(chw.cpu()[None], scale_factor=k, mode="bilinear", align_corners=False)[0]
-        return image.to(self.device, non_blocking=True)
+            # permuted views of contiguous HWC frames are resized straight from HWC
+            hwc = all(c.stride(0) == 1 and c.stride(2) == 3 for c in chws)
+            frames = [(c.permute(1, 2, 0) if hwc else c).to(self.device, non_blocking=True) for c in chws]
+            return resize_u8_device_batch(self.engine, frames, k, src_hwc=hwc)
+        return torch.stack([F.interpolate(c.cpu()[None], scale_factor=k, mode="bilinear", align_corners=False)[0] for c in chws]
+                           ).to(self.device, non_blocking=True)
 
     @torch.no_grad()
     def __call__(self, original_image, bgr=True):
@@ -77,13 +79,12 @@ class DensePosePredictor:
     def predict_batch(self, images, bgr=True):
         """N frames -> N dicts. Frames whose resized size is equal are run as one batch through the kernels."""
         chws = [self._to_chw(im if torch.is_tensor(im) else torch.from_numpy(np.asarray(im)), bgr) for im in images]
-        resized = [self._resize(c) for c in chws]
         groups = {}
-        for i, r in enumerate(resized):
-            groups.setdefault((int(r.shape[1]), int(r.shape[2])), []).append(i)
+        for i, c in enumerate(chws):   # frames of one geometry (a video: run.py:42-57) share the resize launch and the batch
+            groups.setdefault((tuple(c.shape), c.stride(0) == 1 and c.stride(2) == 3), []).append(i)
         out = [None] * len(images)
-        for (h, w), idxs in groups.items():
-            batch = torch.stack([resized[i] for i in idxs])
+        for idxs in groups.values():
+            batch = self._resize_group([chws[i] for i in idxs])
             orig = [(int(chws[i].shape[1]), int(chws[i].shape[2])) for i in idxs]
             res = self.engine.forward_batch(batch, orig, num_streams=self.num_streams if len(idxs) >= 4 else 1)
             if self.check_keep:

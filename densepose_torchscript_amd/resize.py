@@ -48,13 +48,17 @@ def resize_u8_host_model(img_chw, k):
     return np.clip(r, 0, 255).astype(np.uint8)
 
 
-def resize_u8_device(engine, img, k, src_hwc=False):
-    """img: uint8 device tensor [3,H,W] (or [H,W,3] with src_hwc). Returns uint8 [3,oh,ow] on the device."""
-    img = img.contiguous()
+def resize_u8_device_batch(engine, frames, k, src_hwc=False):
+    """frames: list of uint8 device tensors of ONE geometry, each [3,H,W] (or [H,W,3] with src_hwc).
+    Returns uint8 [n,3,oh,ow] on the device: one launch per pass for the whole list, written straight into the batch."""
+    frames = [f.contiguous() for f in frames]
+    f0 = frames[0]
     if src_hwc:
-        H, W = int(img.shape[0]), int(img.shape[1])
+        H, W = int(f0.shape[0]), int(f0.shape[1])
     else:
-        H, W = int(img.shape[1]), int(img.shape[2])
+        H, W = int(f0.shape[1]), int(f0.shape[2])
+    assert all(f.shape == f0.shape and f.dtype == torch.uint8 and f.is_cuda for f in frames)
+    n = len(frames)
     oh, ow = output_size(H, W, k)
     xt, px = axis_table(W, ow, k)
     yt, py = axis_table(H, oh, k)
@@ -64,11 +68,17 @@ def resize_u8_device(engine, img, k, src_hwc=False):
     if key not in cache:  # tables are uploaded once per frame geometry
         cache[key] = (torch.from_numpy(xt).to(dev), torch.from_numpy(yt).to(dev))
     xtab, ytab = cache[key]
-    tmp = torch.empty((3, H, ow), dtype=torch.uint8, device=dev)
-    dst = torch.empty((3, oh, ow), dtype=torch.uint8, device=dev)
+    tmp = torch.empty((n, 3, H, ow), dtype=torch.uint8, device=dev)
+    dst = torch.empty((n, 3, oh, ow), dtype=torch.uint8, device=dev)
     p = L.ResizeParams()
-    p.src, p.tmp, p.dst = img.data_ptr(), tmp.data_ptr(), dst.data_ptr()
+    p.src, p.tmp, p.dst = None, tmp.data_ptr(), dst.data_ptr()
     p.H, p.W, p.oh, p.ow, p.src_hwc = H, W, oh, ow, 1 if src_hwc else 0
     p.xtab, p.ytab, p.xprec, p.yprec = xtab.data_ptr(), ytab.data_ptr(), px, py
-    L.check(engine.lib.dp_resize_u8_bilinear(C.byref(p), engine._stream()), "dp_resize_u8_bilinear")
+    srcs = (C.c_void_p * n)(*[f.data_ptr() for f in frames])
+    L.check(engine.lib.dp_resize_u8_bilinear_batch(C.byref(p), srcs, n, engine._stream()), "dp_resize_u8_bilinear_batch")
     return dst
+
+
+def resize_u8_device(engine, img, k, src_hwc=False):
+    """img: uint8 device tensor [3,H,W] (or [H,W,3] with src_hwc). Returns uint8 [3,oh,ow] on the device."""
+    return resize_u8_device_batch(engine, [img], k, src_hwc)[0]

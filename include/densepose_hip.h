@@ -238,6 +238,9 @@ typedef struct {
   int32_t xprec, yprec; /* weight precision bits of each pass */
 } dp_resize_params;
 int dp_resize_u8_bilinear(const dp_resize_params* p, dp_stream_t stream);
+/* n frames of ONE geometry (a video, run.py:42-57) in one launch per pass: srcs = host array of n device pointers
+ * (p->src is ignored), p->tmp = [n][3][H][ow], p->dst = [n][3][oh][ow] - the batch tensor the engine consumes. */
+int dp_resize_u8_bilinear_batch(const dp_resize_params* p, const void* const* srcs, int n, dp_stream_t stream);
 
 typedef struct {
   const float* coarse; const float* fine; const float* u; const float* v; /* [R][C][S][S] */

@@ -186,6 +186,35 @@ def test_pool_subsample_upsample(eng, dt):
     assert torch.allclose(up.float().cpu().permute(0, 3, 1, 2), 2 * ref, atol=2 * tol)
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 5, 7, 16, 3), (1, 1, 1, 8, 1), (3, 1, 6, 24, 2), (1, 9, 1, 8, 3), (2, 12, 20, 256, 3)])
+def test_merge_upsample2x(eng, dt, shape):
+    """decoder level sum (roi_head.py:71-79): out = base + sum_k bilinear_x2(ups[k]), 2x2-blocked kernel vs torch"""
+    e = eng[dt]
+    N, H, W, Cc, n_ups = shape
+    g = torch.Generator().manual_seed(N * 1000 + H * 100 + W)
+    base = torch.randn((N, Cc, 2 * H, 2 * W), generator=g)
+    ups = [torch.randn((N, Cc, H, W), generator=g) for _ in range(n_ups)]
+    if dt != "fp32":
+        base, ups = _round(base, dt), [_round(u, dt) for u in ups]
+    ref = base.clone()
+    for u in ups:
+        ref = ref + F.interpolate(u, scale_factor=2.0, mode="bilinear", align_corners=False)
+    bt = _nhwc(base, Cc, e.tdt, e.device)
+    uts = [_nhwc(u, Cc, e.tdt, e.device) for u in ups]
+    out = torch.empty_like(bt)
+    arr = (C.c_void_p * n_ups)(*[u.data_ptr() for u in uts])
+    assert e.lib.dp_merge_upsample2x_nhwc(bt.data_ptr(), arr, n_ups, out.data_ptr(), N, H, W, Cc, e.dt, e._stream()) == 0
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    if dt == "fp32":
+        assert torch.allclose(got, ref, atol=2e-6, rtol=0)
+    else:
+        assert torch.allclose(got, _round(ref, dt), atol=4e-2, rtol=1e-2)
+    # in place (out aliases base), as the engine calls it
+    assert e.lib.dp_merge_upsample2x_nhwc(bt.data_ptr(), arr, n_ups, bt.data_ptr(), N, H, W, Cc, e.dt, e._stream()) == 0
+    assert torch.equal(bt, out)
+
+
 def _random_boxes(rng, n, size=400.0, zero_frac=0.05):
     xy = rng.uniform(0, size, (n, 2)).astype(np.float32)
     wh = rng.uniform(2, size / 3, (n, 2)).astype(np.float32)
@@ -405,6 +434,13 @@ def test_resize_and_iuv_extract(eng):
         assert torch.equal(got.cpu(), ref), (H, W)
         got = resize_u8_device(e, img.permute(2, 0, 1).contiguous().to(dev), k, src_hwc=False)
         assert torch.equal(got.cpu(), ref), (H, W)
+    # frames of one geometry in one launch per pass (more than one chunk of 64 frame pointers)
+    from densepose_torchscript_amd.resize import resize_u8_device_batch
+    frames = [torch.from_numpy(rng.integers(0, 256, (60, 90, 3), dtype=np.uint8)) for _ in range(70)]
+    k = min(100 / 60, 140 / 90)
+    got = resize_u8_device_batch(e, [f.to(dev) for f in frames], k, src_hwc=True).cpu()
+    for f, gt in zip(frames, got):
+        assert torch.equal(gt, F.interpolate(f.permute(2, 0, 1)[None], scale_factor=k, mode="bilinear", align_corners=False)[0])
     # IUV extraction (visualizer.py:10-30)
     g = torch.Generator().manual_seed(14)
     R, S = 3, 28

@@ -11,6 +11,7 @@ frames = [torch.from_numpy(np.random.default_rng(1234 + i).integers(0, 256, (800
 for _ in range(2): pred.predict_batch(frames)
 torch.cuda.synchronize()
 eng = pred.engine
+eng.overlap_decoder = False
 eng.prof = []
 t0 = time.perf_counter(); pred.predict_batch(frames); torch.cuda.synchronize(); wall = time.perf_counter() - t0
 rows = {}
