@@ -697,11 +697,177 @@ int launch_conv_ring2(const ConvArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+static int num_cus();
+
+// =====================================================================================================
+// Streaming 1x1 kernel for the HBM-bound pointwise layers (res2/res3/res4 conv3 + residual, block-0 shortcuts, the
+// decoder predictor): 1 tap, stride 1, plain NHWC in/out, 16-bit storage, Cin * 2 B = KP planes of 64 B (KP = 2, 4, 8),
+// Cout a multiple of 256. The generic / ring kernels re-stage the weight tile through LDS for every pixel tile and
+// fetch the pixel tile once per cout tile, so the LDS fill traffic of these layers is 3-4x their HBM bytes, and each
+// workgroup walks a chain of dependent round trips (stage -> barrier -> MFMA -> residual load -> store). Here
+//   * the 256 x K weight slice of the workgroup is staged into LDS ONCE (K-plane images swizzled like the ring planes),
+//   * every wave owns whole 32-pixel x 256-cout tiles (persistent, strided over the pixel range): its pixel fragments
+//     are plain 16-byte global loads straight into the MFMA B-operand registers - no LDS, no barrier in the loop -,
+//   * the registers of the pixel fragments and of the residual are refilled IN PLACE with the wave's next tile right
+//     after their last use, so the next tile's loads fly during the current tile's MFMAs, epilogue and stores.
+// Wave tile = 16 cout tiles x 2 pixel tiles = 128 accumulator registers; one workgroup (4 waves) per CU.
+// =====================================================================================================
+template <typename T, int KP>
+__global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const ConvArgs p) {
+  static_assert(sizeof(T) == 2, "16-bit storage only (fp32 parity mode stays on the generic kernels)");
+  constexpr int TP = 2;                 // 32 pixels per wave tile
+  constexpr int NB = 4;                 // 64-cout blocks per wave (256 couts)
+  constexpr int W_PLANE = 256 * 64;     // bytes of one K plane of the weight slice
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const bias_s = reinterpret_cast<float*>(smem + KP * W_PLANE);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.y * 256;
+
+  // ---- weights of this cout slice -> LDS, once: piece = (plane kp, 16-row group rg), 1 KiB per wave-instruction
+  {
+    const int srow = lane >> 2;
+    const int scc = (lane & 3) ^ swz(srow);
+    const T* __restrict__ wbase = reinterpret_cast<const T*>(p.weight) + (long long)(n0 + srow) * p.Kpad + scc * 8;
+    for (int piece = wave; piece < KP * 16; piece += 4) {
+      const int kp = piece >> 4, rg = piece & 15;
+      const T* src = wbase + (long long)(rg * 16) * p.Kpad + kp * 32;
+      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(src), DP_LDS_PTR(smem + kp * W_PLANE + rg * 1024), 16, 0, 0);
+    }
+    bias_s[tid] = p.bias[n0 + tid];
+  }
+  __syncthreads();  // (vmcnt(0) + barrier)
+
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+  const unsigned char* const rd_w = smem + fr * 64 + ((fq ^ swz(fr)) << 4);
+  const int n_wt = (p.M + 31) >> 5;                  // 32-pixel wave tiles
+  const int wt_step = gridDim.x * 4;
+  int wt = blockIdx.x * 4 + wave;
+  if (wt >= n_wt) return;
+
+  // Buffer resources sized to the M real pixel rows: a row >= M (tail of the last tile, or the "next tile" of a wave that
+  // has none) is out of range, so its loads return zeros without touching memory and its stores are dropped - no
+  // clamping or predication, 32-bit offsets with the plane / run displacement in the instruction's immediate.
+  const bool has_res = p.residual != nullptr;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(has_res ? p.residual : p.in), 0, has_res ? (unsigned)((long long)p.M * p.rsW * 2) : 0u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)((long long)p.M * p.osW * 2), 0x00020000);
+  const int in_pitch = p.Cin * 2, res_pitch = (int)p.rsW * 2, out_pitch = (int)p.osW * 2;
+  const int col_b = (n0 + fq * 8) * 2;   // byte offset of this lane's first run inside a pixel's channel row
+
+  u32x4 a[KP][TP];        // pixel fragments (MFMA B operand): pixel fr of tile j, K chunk fq of plane kp
+  u32x4 r[TP][NB * 2];    // residual: the 8 runs of 8 consecutive couts this lane stores per pixel
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    const int m = wt * 32 + j * 16 + fr;
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) a[kp][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, m * in_pitch + fq * 16 + kp * 64, 0, 0);
+    if (has_res) {
+#pragma unroll
+      for (int q = 0; q < NB * 2; ++q) r[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, m * res_pitch + col_b + q * 64, 0, 0);
+    }
+  }
+
+  for (; wt < n_wt; wt += wt_step) {
+    int m_cur[TP], m_nxt[TP];
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+      m_cur[j] = wt * 32 + j * 16 + fr;
+      m_nxt[j] = m_cur[j] + wt_step * 32;    // next tile of this wave (past the end: out of range, see above)
+    }
+    f32x4 acc[NB][4][TP];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        u32x4 wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const u32x4*>(rd_w + kp * W_PLANE + (b * 64 + i * 16) * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < TP; ++j) Mma<T>::run(wf[i], a[kp][j], acc[b][i][j]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the weight fragments of one cout block live at a time
+      }
+      // plane kp of the current tile is consumed: refill its registers with the next tile
+#pragma unroll
+      for (int j = 0; j < TP; ++j) a[kp][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, m_nxt[j] * in_pitch + fq * 16 + kp * 64, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- epilogue: lane = pixel fr of tile j, runs of 8 consecutive couts (store_tile's layout, 4 cout blocks)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+      const int o_off = m_cur[j] * out_pitch + col_b;
+      const int r_off = m_nxt[j] * res_pitch + col_b;
+#pragma unroll
+      for (int q = 0; q < NB * 2; ++q) {
+        const int b = q >> 1, h = q & 1;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + q * 32 + fq * 8);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_s + q * 32 + fq * 8 + 4);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[k] = acc[b][2 * h][j][k] + b0[k];
+          v[4 + k] = acc[b][2 * h + 1][j][k] + b1[k];
+        }
+        if (has_res) {
+          const u32x4 rv = r[j][q];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[2 * k] += Elem<T>::unpack(rv[k] & 0xffffu);
+            v[2 * k + 1] += Elem<T>::unpack(rv[k] >> 16);
+          }
+          r[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, r_off + q * 64, 0, 0);  // the next tile's run
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        u32x4 pk;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pk[k] = Elem<T>::pack2(v[2 * k], v[2 * k + 1]);
+        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, o_off + q * 64, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
+template <typename T, int KP>
+int launch_conv_stream(const ConvArgs& a, hipStream_t stream) {
+  if constexpr (sizeof(T) != 2) {
+    return dp_fail(DP_ERR_UNSUPPORTED, "conv1x1_stream_kernel: 16-bit storage only");
+  } else {
+    constexpr int lds = KP * 256 * 64 + 256 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel<T, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set = true;
+    }
+    const int slices = a.Cout / 256;
+    const int n_wt = (a.M + 31) / 32;
+    int gx = (num_cus() + slices - 1) / slices;   // one workgroup per CU over all slices
+    if (gx > (n_wt + 3) / 4) gx = (n_wt + 3) / 4;
+    hipLaunchKernelGGL((conv1x1_stream_kernel<T, KP>), dim3(gx, slices), dim3(256), lds, stream, a);
+    return dp_check_launch("conv1x1_stream_kernel");
+  }
+}
+
 // Kernel choice (measured on MI355X, profiles/): the LDS-ring kernels need a 64-byte K plane to lie inside one tap;
 // the 256x256 ring tile is ~1.15x the 128x128 ring tile when both fill the chip, so the shape is picked by
 // wave-quantisation efficiency (workgroups / (CUs x resident workgroups per CU), rounded up to whole rounds);
 // short-K layers are HBM/latency bound and run on the generic kernel with 64-byte steps (4 workgroups per CU).
-enum { DP_CONV_K64 = 0, DP_CONV_K128 = 1, DP_CONV_RING256 = 2, DP_CONV_RING128 = 3, DP_CONV_RING256x128 = 4 };
+enum { DP_CONV_K64 = 0, DP_CONV_K128 = 1, DP_CONV_RING256 = 2, DP_CONV_RING128 = 3, DP_CONV_RING256x128 = 4, DP_CONV_STREAM = 5 };
 
 static int num_cus() {
   static int n = 0;
@@ -724,14 +890,24 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   const bool ring_ok = (p->Cin * es) % 64 == 0 && p->ntaps >= 1 && p->ntaps <= 32 &&
                        (long long)p->N * p->H * p->W * p->Cin * es < (1ll << 31) && (long long)p->Cout_w * p->Kpad * es < (1ll << 31);
   const bool big_ok = ring_ok && p->Cout % 256 == 0 && p->Cout_w % 256 == 0;
-  const char* fe = getenv("DP_CONV_BIG");  // test/debug knob - 0: generic only, 1: 256x256 ring whenever legal, 2: 128x128 ring whenever legal
+  // streaming 1x1: pointwise, stride 1, plain NHWC tensors, 16-bit storage, K = 2 / 4 / 8 planes, Cout in 256-slices
+  const int kb = p->Cin * es;
+  const bool lin_out = p->osH == (long long)p->Wo * p->osW && p->osN == (long long)p->Ho * p->osH;
+  const bool lin_res = !p->residual || (p->rshift == 0 && p->rsH == (long long)p->Wo * p->rsW && p->rsN == (long long)p->Ho * p->rsH);
+  const bool stream_ok = es == 2 && p->ntaps == 1 && p->stride == 1 && p->hi_off == 0 && p->wi_off == 0 && p->H == p->Ho && p->W == p->Wo &&
+                         (kb == 128 || kb == 256 || kb == 512) && p->Kpad == p->Cin && p->Cout % 256 == 0 && p->Cout_w % 256 == 0 &&
+                         !p->out_f32 && lin_out && lin_res && M >= 4096;
+  const char* fe = getenv("DP_CONV_BIG");  // test/debug knob - 0: generic only, 1: 256x256 ring whenever legal, 2: 128x128 ring whenever legal, 5: streaming 1x1 whenever legal
   if (fe) {
     const int f = atoi(fe);
+    if (f == 5 && stream_ok) return DP_CONV_STREAM;
     if (f == 1 && big_ok) return DP_CONV_RING256;
     if (f == 2 && ring_ok) return DP_CONV_RING128;
     if (f == 3 && ring_ok && p->Cout > 64) return DP_CONV_RING256x128;
     return DP_CONV_K128;
   }
+  const char* se = getenv("DP_CONV_STREAM");   // A/B knob: 0 disables the streaming 1x1 kernel
+  if (stream_ok && !(se && atoi(se) == 0)) return DP_CONV_STREAM;
   if (!ring_ok) return DP_CONV_K128;
   if ((long long)p->Kpad * es < 1024) return DP_CONV_K128;   // short K: see above
   // Calibrated on the real layer shapes (scratch/conv_sweep.py, MI355X): the 256x256 ring tile wins whenever it has at
@@ -805,6 +981,14 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   a.res_linear = (p->residual && p->rshift == 0 && p->rsH == (long long)p->Wo * p->rsW && p->rsN == (long long)p->Ho * p->rsH) ? 1 : 0;
   hipStream_t s = as_stream(stream);
   const int kc = choose_conv_kernel(p, M);
+  if (kc == DP_CONV_STREAM) {
+    a.tiles_n = p->Cout / 256;
+    a.n_tiles = 0;
+    const int kp = p->Cin * es / 64;
+    if (kp == 2) { DP_BY_DTYPE((launch_conv_stream<T, 2>(a, s))); }
+    if (kp == 4) { DP_BY_DTYPE((launch_conv_stream<T, 4>(a, s))); }
+    DP_BY_DTYPE((launch_conv_stream<T, 8>(a, s)));
+  }
   if (kc == DP_CONV_RING256) {
     a.tiles_n = p->Cout / 256;
     a.n_tiles = (int)((M + 255) / 256) * a.tiles_n;

@@ -84,8 +84,8 @@ typedef struct {
   int32_t hi_off, wi_off; /* input pixel of output (ho,wo), tap (dy,dx): (ho*stride + hi_off + dy, wo*stride + wi_off + dx) */
 } dp_conv_params;
 int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
-/* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile, 3 = 128x128 LDS-ring tile
- * (profiling / roofline bookkeeping only) */
+/* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile,
+ * 3 = 128x128 LDS-ring tile, 4 = 256x128 two-workgroup ring tile, 5 = streaming 1x1 (resident weights) - profiling / roofline bookkeeping only */
 int dp_conv2d_kernel_class(const dp_conv_params* p);
 
 /* K3  resnet.py:353  F.max_pool2d(k=3, s=2, p=1), NHWC */

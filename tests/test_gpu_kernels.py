@@ -66,6 +66,32 @@ def test_conv2d_ring_kernels(eng, dt, case, force, monkeypatch):
     test_conv2d_matches_torch(eng, dt, case)
 
 
+STREAM_CASES = [
+    # pointwise, stride 1, Cin*2 B in {128, 256, 512}, Cout % 256 == 0, M >= 4096: the streaming 1x1 kernel (storage-type output)
+    (2, 64, 50, 45, 256, 1, 1, 0, 1, True, True),      # res2 conv3 shape class, M = 4500 (ragged last tile)
+    (3, 64, 40, 37, 256, 1, 1, 0, 1, False, False),    # block-0 shortcut
+    (1, 128, 70, 61, 512, 1, 1, 0, 1, True, True),     # res3 conv3: two cout slices
+    (1, 256, 65, 64, 256, 1, 1, 0, 1, False, False),   # decoder predictor
+    (1, 256, 66, 63, 1024, 1, 1, 0, 1, True, True),    # res4 conv3: four cout slices
+]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", STREAM_CASES)
+def test_conv2d_stream_kernel(eng, dt, case, monkeypatch):
+    from densepose_torchscript_amd import lib as L
+    monkeypatch.setenv("DP_CONV_BIG", "5")
+    orig = eng[dt].lib.dp_conv2d_kernel_class
+    test_conv2d_matches_torch(eng, dt, case)
+    # the storage-type launch of this shape really is the streaming kernel (class 5)
+    p = L.ConvParams()
+    N, Cin, H, W, Cout = case[:5]
+    p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, Cin, H, W, Cout, Cout, Cin
+    p.stride, p.ntaps, p.dtype, p.out_f32 = 1, 1, eng[dt].dt, 0
+    p.osN, p.osH, p.osW = H * W * Cout, W * Cout, Cout
+    assert orig(C.byref(p)) == 5
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_matches_torch(eng, dt, case):
