@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--dets", type=int, default=8, help="detections per image (R), pinned via TEST.DETECTIONS_PER_IMAGE")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
-    ap.add_argument("--streams", type=int, default=2, help="sub-batches of a step run concurrently on this many HIP streams")
+    ap.add_argument("--streams", type=int, default=1, help="sub-batches of a step run concurrently on this many HIP streams")
     ap.add_argument("--no-overlap", action="store_true", help="decoder in line instead of on a side stream")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-instrumented roofline pass (profiling runs)")

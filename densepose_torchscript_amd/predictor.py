@@ -21,7 +21,7 @@ from .weights import check_state, load_checkpoint
 
 
 class DensePosePredictor:
-    def __init__(self, cfg, weights, dtype="bf16", device="cuda:0", resize="host", num_streams=2, use_graphs=False, check_keep=False):
+    def __init__(self, cfg, weights, dtype="bf16", device="cuda:0", resize="host", num_streams=1, use_graphs=False, check_keep=False):
         """cfg: ModelConfig | variant name | yaml path. weights: path to .pkl/.pth or a canonical state dict."""
         if not isinstance(cfg, ModelConfig):
             cfg = get_config(cfg)

@@ -204,6 +204,13 @@ def test_zero_and_many_detections():
             assert tuple(out[k].shape) == tuple(ref[k].shape) and out[k].dtype == ref[k].dtype, (k, out[k].shape, ref[k].shape)
         if R:
             assert (out["pred_densepose_u"].cpu() - ref["pred_densepose_u"]).abs().max().item() <= IUV_ATOL
+            # the side-stream decoder is pure scheduling: bit-identical results without it
+            plain = DensePosePredictor(cfg, state, dtype="fp32")
+            plain.engine.overlap_decoder = False
+            out2 = plain(img)
+            torch.cuda.synchronize()
+            for k in out:
+                assert torch.equal(out[k].cpu(), out2[k].cpu()), k
 
 
 def test_video_frame_geometry_and_chw_input():

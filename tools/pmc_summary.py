@@ -14,14 +14,21 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(conv_ring_kernel|conv_igemm_kernel)<([^>]*)>", name)
+    m = re.search(r"(conv_ring2_kernel|conv_ring_kernel|conv_igemm_kernel|conv1x1_stream_kernel)<([^>]*)>", name)
     if m:
         args = [a.strip() for a in m.group(2).split(",")]
-        dt = "bf16" if args[0] == "unsigned short" else "f32"
+        dt = {"unsigned short": "bf16", "_Float16": "f16", "float": "f32"}.get(args[0], args[0])
         if m.group(1) == "conv_ring_kernel":
             return "conv_ring_kernel<%s>[%s]" % ("256x256" if args[1] == "4" else "128x128", dt)
+        if m.group(1) == "conv_ring2_kernel":
+            return "conv_ring2_kernel<256x128>[%s]" % dt
+        if m.group(1) == "conv1x1_stream_kernel":
+            return "conv1x1_stream_kernel[%s]" % dt
         return "conv_igemm_kernel<%s>[%s]" % (args[1], dt)
     m = re.search(r"::(\w+)(<|\()", name)
+    if m:
+        return m.group(1)
+    m = re.search(r"(\w+)(<|\()", name)
     return m.group(1) if m else name[:60]
 
 
