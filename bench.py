@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--streams", type=int, default=1, help="sub-batches of a step run concurrently on this many HIP streams")
+    ap.add_argument("--pipeline", type=int, default=2, help="stream lanes consecutive batches alternate between (1 = off)")
     ap.add_argument("--no-overlap", action="store_true", help="decoder in line instead of on a side stream")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-instrumented roofline pass (profiling runs)")
@@ -116,14 +117,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # Timed region: consecutive batches alternate between `--pipeline` stream lanes, so the DensePose-head phase of batch i
+    # (launched once the host has read batch i's detection counts) runs beside the backbone / RPN phase of batch i+1.
+    # Every batch is complete when the closing device synchronize returns; nothing is skipped or carried over.
+    pipelined = not (args.streams == 1 and args.no_graphs)
+    pred.pipeline_depth = args.pipeline if pipelined else 1
+    for _ in range(max(args.warmup, 2 * pred.pipeline_depth)):   # at least one capture + one replay per lane
         out = step()
     barrier()
     t_begin = time.perf_counter()
     for _ in range(args.steps):
-        out = step()   # steps are not separated by a device sync: batch i+1's resize / backbone queue behind batch i's head
+        out = step()
+    pred.join()
     barrier()
     elapsed = time.perf_counter() - t_begin
+    pred.pipeline_depth = 1   # the latency loop and the roofline pass below run batch after batch on one stream
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -198,7 +206,10 @@ def main():
             "config": {"workload": "%s batch=%d/GPU %dx%d uint8 frames resident in HBM, R=%d detections/img (measured %s), synthetic seeded weights"
                                    % (args.config, args.batch, hw[0], hw[1], args.dets, dets),
                        "global_batch": args.batch * world, "parallelism": "frame-sharded dp%d, no hot-loop collective" % world,
-                       "alg_gflop_per_image": round(flops_step / args.batch / 1e9, 1)},
+                       "alg_gflop_per_image": round(flops_step / args.batch / 1e9, 1),
+                       "schedule": "%d batch stream(s), %s, decoder %s, %d pipeline lane(s)"
+                                   % (args.streams, "eager launches" if args.no_graphs else "HIP-graph replay of the static part",
+                                      "on a side stream" if overlap else "in line", args.pipeline if pipelined else 1)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

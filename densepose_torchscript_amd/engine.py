@@ -462,6 +462,9 @@ class Engine:
         """DensePose branch (sized by the detection counts R - the one host read-back of the path) + postprocess."""
         n, h, w = st["n"], st["h"], st["w"]
         det_boxes, det_scores, det_counts = st["det_boxes"], st["det_scores"], st["det_counts"]
+        # the returned `scores` are slices of this tensor: with graph replay st[...] lives in the graph's memory pool and is
+        # overwritten by the next replay, so the results get their own copy (n x D floats)
+        det_scores = det_scores.clone()
         st["counts_event"].synchronize()
         counts_host = st["counts_pinned"].numpy().astype(np.int64)
         coarse, fine, u, v, offs = self.densepose_branch(st["feats"], det_boxes, det_counts, counts_host, st.get("dec"))
@@ -495,7 +498,7 @@ class Engine:
         return results, (keep, counts_host)
 
     @torch.no_grad()
-    def forward_batch(self, images_u8, orig_hw, given_boxes=None, num_streams=1):
+    def forward_batch(self, images_u8, orig_hw, given_boxes=None, num_streams=1, slot=0):
         """images_u8: uint8 [n,3,h,w] on the device (already resized, defaults.py:89). orig_hw: list of (H, W).
         Returns a list of n dicts with the reference's 8 keys (postprocessing.py:52-61).
 
@@ -507,7 +510,7 @@ class Engine:
         self.inter = {}
         g = max(1, min(int(num_streams), n)) if given_boxes is None else 1
         if g == 1:
-            st = self._phase_a_run(images_u8, 0, given_boxes)
+            st = self._phase_a_run(images_u8, ("lane", slot), given_boxes)   # one HIP graph instance per pipeline lane
             results, keep = self._phase_b(st, orig_hw)
             self._pending_keep = [(keep, 0)]
             return results

@@ -21,7 +21,8 @@ from .weights import check_state, load_checkpoint
 
 
 class DensePosePredictor:
-    def __init__(self, cfg, weights, dtype="bf16", device="cuda:0", resize="host", num_streams=1, use_graphs=False, check_keep=False):
+    def __init__(self, cfg, weights, dtype="bf16", device="cuda:0", resize="host", num_streams=1, use_graphs=False, check_keep=False,
+                 pipeline_depth=1):
         """cfg: ModelConfig | variant name | yaml path. weights: path to .pkl/.pth or a canonical state dict."""
         if not isinstance(cfg, ModelConfig):
             cfg = get_config(cfg)
@@ -42,6 +43,10 @@ class DensePosePredictor:
         # non-finite boxes were filtered before NMS. The flags are still computed on the device; reading them back costs a
         # device synchronisation per batch, so it is opt-in (tests run with check_keep=True).
         self.check_keep = check_keep
+        # > 1: consecutive predict_batch calls alternate between this many streams without joining the caller's stream
+        # (see predict_batch / join); 1 = every call is ordered on the caller's stream like the reference's module call
+        self.pipeline_depth = pipeline_depth
+        self._lanes, self._next_lane = [], 0
 
     # -- defaults.py:76-89 ---------------------------------------------------------------------------------
     def _to_chw(self, original_image, bgr):
@@ -77,18 +82,49 @@ class DensePosePredictor:
 
     @torch.no_grad()
     def predict_batch(self, images, bgr=True):
-        """N frames -> N dicts. Frames whose resized size is equal are run as one batch through the kernels."""
+        """N frames -> N dicts. Frames whose resized size is equal are run as one batch through the kernels.
+
+        With ``pipeline_depth > 1`` consecutive calls alternate between that many HIP streams ("lanes") and the caller's
+        stream is NOT made to wait for the lane: the DensePose-head phase of one batch (launched after the host read the
+        detection counts) then runs beside the backbone / RPN phase of the next batch, which fills the partial last
+        rounds of its launches. The returned tensors are valid once ``join()`` (or a device synchronize) has been called."""
         chws = [self._to_chw(im if torch.is_tensor(im) else torch.from_numpy(np.asarray(im)), bgr) for im in images]
         groups = {}
         for i, c in enumerate(chws):   # frames of one geometry (a video: run.py:42-57) share the resize launch and the batch
             groups.setdefault((tuple(c.shape), c.stride(0) == 1 and c.stride(2) == 3), []).append(i)
         out = [None] * len(images)
+        cur = torch.cuda.current_stream(self.device)
         for idxs in groups.values():
-            batch = self._resize_group([chws[i] for i in idxs])
-            orig = [(int(chws[i].shape[1]), int(chws[i].shape[2])) for i in idxs]
-            res = self.engine.forward_batch(batch, orig, num_streams=self.num_streams if len(idxs) >= 4 else 1)
-            if self.check_keep:
-                res = self.engine.apply_keep_filter(res)
+            lane, stream = 0, cur
+            if self.pipeline_depth > 1:
+                if len(self._lanes) < self.pipeline_depth:
+                    self._lanes = [torch.cuda.Stream(device=self.device) for _ in range(self.pipeline_depth)]
+                lane = self._next_lane
+                self._next_lane = (lane + 1) % self.pipeline_depth
+                stream = self._lanes[lane]
+                ready = torch.cuda.Event()
+                ready.record(cur)          # the frames are ready on the caller's stream
+                stream.wait_event(ready)
+                for i in idxs:
+                    if chws[i].is_cuda:
+                        chws[i].record_stream(stream)   # the caller may drop its frames as soon as this call returns
+            with torch.cuda.stream(stream):
+                batch = self._resize_group([chws[i] for i in idxs])
+                orig = [(int(chws[i].shape[1]), int(chws[i].shape[2])) for i in idxs]
+                res = self.engine.forward_batch(batch, orig, num_streams=self.num_streams if len(idxs) >= 4 else 1, slot=lane)
+                if self.check_keep:
+                    res = self.engine.apply_keep_filter(res)
+            if stream is not cur:
+                for r in res:
+                    for t in r.values():
+                        if t.is_cuda:
+                            t.record_stream(cur)   # the caller will read them on its own stream after join()
             for i, r in zip(idxs, res):
                 out[i] = r
         return out
+
+    def join(self):
+        """Make the caller's stream wait for every pipeline lane (no host synchronisation)."""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self._lanes:
+            cur.wait_stream(s)

@@ -177,12 +177,37 @@ def test_streams_and_graphs_do_not_change_results():
     base = DensePosePredictor(cfg, state, dtype="fp32", num_streams=1).predict_batch(imgs)
     for streams, graphs in ((2, False), (3, True), (1, True)):
         pred = DensePosePredictor(cfg, state, dtype="fp32", num_streams=streams, use_graphs=graphs)
-        for _ in range(3):  # 1st call captures, later calls replay
-            out = pred.predict_batch(imgs)
+        first = pred.predict_batch(imgs)   # 1st call captures, later calls replay
+        for _ in range(2):
+            out = pred.predict_batch(imgs[::-1])   # other inputs through the same graph: must not disturb `first`
+        out = pred.predict_batch(imgs)
         torch.cuda.synchronize()
-        for a, b in zip(base, out):
-            for k in a:
-                assert torch.equal(a[k].cpu(), b[k].cpu()), (streams, graphs, k)
+        for res in (first, out):
+            for a, b in zip(base, res):
+                for k in a:
+                    assert torch.equal(a[k].cpu(), b[k].cpu()), (streams, graphs, k)
+
+
+def test_pipeline_lanes_do_not_change_results():
+    """pipeline_depth = 2: consecutive batches alternate between two stream lanes (own HIP graph instance each) and the
+    caller's stream only waits in join(); outputs are bit-identical to the plain one-stream calls."""
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    meta, z = load_golden("tiny_r50_s1x_a")
+    cfg, state, img = golden_case_inputs(meta)
+    rng = np.random.default_rng(7)
+    batches = [[torch.from_numpy(rng.integers(0, 256, (96, 160, 3), dtype=np.uint8)).cuda() for _ in range(4)] for _ in range(5)]
+    plain = DensePosePredictor(cfg, state, dtype="fp32", resize="device")
+    want = [plain.predict_batch(b) for b in batches]
+    torch.cuda.synchronize()
+    for graphs in (False, True):
+        pred = DensePosePredictor(cfg, state, dtype="fp32", resize="device", use_graphs=graphs, pipeline_depth=2)
+        got = [pred.predict_batch(b) for b in batches]   # lanes 0,1,0,1,0: graph capture on first use of a lane, replays after
+        pred.join()
+        torch.cuda.current_stream().synchronize()
+        for w, g in zip(want, got):
+            for a, b in zip(w, g):
+                for k in a:
+                    assert torch.equal(a[k].cpu(), b[k].cpu()), (graphs, k)
 
 
 def test_zero_and_many_detections():
