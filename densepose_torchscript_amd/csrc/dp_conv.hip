@@ -896,7 +896,9 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   const bool lin_res = !p->residual || (p->rshift == 0 && p->rsH == (long long)p->Wo * p->rsW && p->rsN == (long long)p->Ho * p->rsH);
   const bool stream_ok = es == 2 && p->ntaps == 1 && p->stride == 1 && p->hi_off == 0 && p->wi_off == 0 && p->H == p->Ho && p->W == p->Wo &&
                          (kb == 128 || kb == 256 || kb == 512) && p->Kpad == p->Cin && p->Cout % 256 == 0 && p->Cout_w % 256 == 0 &&
-                         !p->out_f32 && lin_out && lin_res && M >= 4096;
+                         !p->out_f32 && lin_out && lin_res && M >= 4096 &&
+                         // 32-bit buffer offsets, rows up to one grid stride of tiles past the end are addressed
+                         (M + (1ll << 16)) * 2 * (p->Cin > p->osW ? p->Cin : (p->osW > p->rsW ? p->osW : p->rsW)) < (1ll << 31);
   const char* fe = getenv("DP_CONV_BIG");  // test/debug knob - 0: generic only, 1: 256x256 ring whenever legal, 2: 128x128 ring whenever legal, 5: streaming 1x1 whenever legal
   if (fe) {
     const int f = atoi(fe);

@@ -115,6 +115,31 @@ def test_batch_equals_single_calls():
             assert torch.equal(single[k].cpu(), b[k].cpu()), k
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_full_width_batch_equals_single_calls_16bit(dtype):
+    """Same property at full channel width in the 16-bit modes, where every conv kernel family is in play (256x256 /
+    256x128 / 128x128 ring tiles, streaming 1x1, generic): a frame's result does not depend on what else is in the batch
+    (tiles that span two frames, persistent waves that walk across frames), graph replay and pipeline lanes included."""
+    from densepose_torchscript_amd import get_config, make_synthetic_state
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    cfg = get_config("densepose_rcnn_R_50_FPN_s1x", ["INPUT.MIN_SIZE_TEST", 256, "INPUT.MAX_SIZE_TEST", 400, "TEST.DETECTIONS_PER_IMAGE", 6])
+    state = make_synthetic_state(cfg, 3)
+    rng = np.random.default_rng(11)
+    imgs = [torch.from_numpy(rng.integers(0, 256, (256, 400, 3), dtype=np.uint8)).cuda() for _ in range(6)]
+    single = DensePosePredictor(cfg, state, dtype=dtype, resize="device")
+    want = [single(im) for im in imgs]
+    torch.cuda.synchronize()
+    batched = DensePosePredictor(cfg, state, dtype=dtype, resize="device", use_graphs=True, pipeline_depth=2)
+    for order in (list(range(6)), [5, 0, 3, 1, 4, 2]):
+        got = batched.predict_batch([imgs[i] for i in order])
+        batched.join()
+        torch.cuda.synchronize()
+        for i, g in zip(order, got):
+            for k in g:
+                assert torch.equal(want[i][k].cpu(), g[k].cpu()), (dtype, order, i, k)
+    assert sum(int(w["scores"].shape[0]) for w in want) > 0
+
+
 def test_device_resize_equals_host_resize():
     meta, z, cfg, pred, out_h = _run("tiny_r50_s1x_b", "fp32", resize="host")
     _, _, _, _, out_d = _run("tiny_r50_s1x_b", "fp32", resize="device")
