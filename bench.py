@@ -147,10 +147,11 @@ def main():
     flops_step = eng.flops_last
 
     # ---- roofline of the dominant kernel: K further steps of the same workload, every conv launch bracketed by HIP events
-    # on the stream it is launched on. This pass runs the batch on ONE stream without graph replay, so each kernel has the
-    # chip to itself and the event delta is its own duration (in the timed region two sub-batches overlap on two streams,
-    # which inflates per-launch durations by the time spent sharing the CUs). profiles/ holds the rocprofv3 summary of the
-    # same serialized configuration (`--streams 1 --no-graphs`), whose per-kernel averages must agree with these.
+    # on the stream it is launched on. This pass is fully serialized - one stream, no graph replay, no side stream, no
+    # pipeline lane - so each kernel has the chip to itself and the event delta is its own duration (in the timed region the
+    # decoder and the next batch share the chip with the launch being timed, which inflates per-launch durations).
+    # profiles/ holds the rocprofv3 summary of the same serialized configuration (`--streams 1 --no-graphs`), whose
+    # per-kernel averages must agree with these.
     if args.no_roofline:
         if rank == 0:
             print(json.dumps({"value": round(args.batch * world * args.steps / elapsed, 3), "ms_per_step": round(1e3 * elapsed / args.steps, 3)}), flush=True)
@@ -187,6 +188,8 @@ def main():
                 "launches_per_step": dcalls // args.steps, "avg_launch_us": round(1e6 * dsec / dcalls, 2),
                 "alg_gflop_per_launch": round(dflops / dcalls / 1e9, 3),
                 "share_of_serialized_step": round(dsec / args.steps / t_ser, 3),
+                # all convolution FLOPs of a step over the step time of the timed region (every kernel included, not a kernel roofline)
+                "whole_step_tflops": round(flops_step / (elapsed / args.steps) / 1e12, 1),
                 "measured": "K event-instrumented steps on one stream (kernels alone on the chip), %.2f ms/step serialized" % (1e3 * t_ser),
                 "all_conv_classes": {c: {"tflops": round(v[0] / v[1] / 1e12, 2), "calls_per_step": v[2] // args.steps,
                                          "ms_per_step": round(1e3 * v[1] / args.steps, 3)} for c, v in agg.items()}}
