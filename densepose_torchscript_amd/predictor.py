@@ -27,7 +27,7 @@ class DensePosePredictor:
         if not isinstance(cfg, ModelConfig):
             cfg = get_config(cfg)
         self.cfg = cfg
-        state = load_checkpoint(weights) if isinstance(weights, str) else weights
+        state = load_checkpoint(weights, cfg) if isinstance(weights, str) else weights
         check_state(cfg, state)
         assert cfg.input_format in ("RGB", "BGR"), cfg.input_format
         self.input_format = cfg.input_format

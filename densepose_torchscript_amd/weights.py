@@ -4,9 +4,10 @@
   ``.pkl`` files the reference loads (/root/reference/detectron2/checkpoint/detection_checkpoint.py:49-56;
   module layout from backbone/resnet.py:609-689, fpn.py:72-100, rpn.py:97-113, box_head.py:70-75,
   fast_rcnn.py:200-203, densepose roi_head.py:42-68, v1convx.py:36-41, deeplab.py:33-60,117-137, chart.py:45-59).
-* ``load_checkpoint(path)`` - ``.pkl`` (pickle, latin1, ``{"model": {name: ndarray}, "__author__": ...}``)
+* ``load_checkpoint(path, cfg)`` - ``.pkl`` (pickle, latin1, ``{"model": {name: ndarray}, "__author__": ...}``)
   or a torch ``.pth`` state dict; accepts the TorchScript fork's ModuleList alias spellings
-   and the ``model.`` prefix of ``DefaultPredictor.state_dict()``.
+   and the ``model.`` prefix of ``DefaultPredictor.state_dict()``; Caffe2 / Detectron1 blob
+  pickles are renamed by ``c2_names.py`` (c2_model_loading.py:66-204).
 * ``make_synthetic_state(cfg, seed)`` - seeded weights whose activations stay O(1) on 0..255 pixel
   input (there are no pretrained checkpoints and no network in the build/bench boxes).
 """
@@ -144,16 +145,24 @@ def canonical_name(key):
     return key
 
 
-def load_checkpoint(path):
-    """-> OrderedDict canonical name -> float32 ndarray (pixel_mean/std and cell_anchors dropped)."""
+def load_checkpoint(path, cfg=None):
+    """-> OrderedDict canonical name -> float32 ndarray (pixel_mean/std and cell_anchors dropped).
+    Caffe2 / Detectron1 pickles (no "model" + "__author__" pair: detection_checkpoint.py:53-64) need ``cfg`` to name
+    the target variant; they are renamed by ``c2_names.convert_caffe2_blobs``."""
     if path.endswith(".pkl"):
         with open(path, "rb") as f:
             data = pickle.load(f, encoding="latin1")
-        if "model" in data:
+        if "model" in data and "__author__" in data:
             data = data["model"]
-        elif "blobs" in data:
-            raise ValueError("Caffe2/Detectron1 checkpoints are out of scope (SURVEY row 6); "
-                             "convert with detectron2 first")
+        elif "model" in data and isinstance(data["model"], dict):
+            data = data["model"]
+        else:
+            from .c2_names import convert_caffe2_blobs
+            if cfg is None:
+                raise ValueError("%s is a Caffe2/Detectron1 checkpoint: pass the model config so that its blobs can be renamed" % path)
+            blobs = data["blobs"] if "blobs" in data else data
+            blobs = {k: v for k, v in blobs.items() if not k.endswith("_momentum")}
+            return convert_caffe2_blobs(blobs, param_shapes(cfg))
     else:
         import torch
         data = torch.load(path, map_location="cpu")
