@@ -5,21 +5,30 @@
 // Replaces every F.conv2d / nn.Linear / ConvTranspose2d call site of the reference's hot path
 // (detectron2/layers/wrappers.py:105-111 and the callers listed in include/densepose_hip.h).
 //
-// Design (wave64, 4 waves per workgroup, 128 pixels x {128|64} couts per workgroup, K-step = 128 bytes):
-//   * the weight tile is the MFMA "A" operand (rows = couts) and the im2col pixel tile the "B" operand
-//     (cols = pixels): the 16x16 accumulator then holds 4 CONSECUTIVE channels of one pixel per lane, so
-//     the NHWC epilogue stores 8/16 contiguous bytes per lane with bias/residual/ReLU fused.
-//   * both tiles are staged global -> registers -> LDS (16-byte chunks), double buffered: the loads of
-//     K-step t+1 are issued before the MFMAs of step t and written to the other buffer after them, one
-//     barrier per K-step. Zero padding / ragged M / K padding are handled by predicating the 16-byte load.
-//   * LDS image: two planes of [rows][64 B]; chunk c of row r sits at slot c ^ ((-(r>>2))&3), plane 1 also
-//     swaps row pairs (r^1): ds_write_b128 and the fragment ds_read_b128 are both bank-conflict free.
-//   * the K axis is table driven (ktab: {dy, dx, c0, valid} per 16-byte chunk), so 1x1 / 3x3 / dilated /
-//     7x7-stem / 2x2 sub-pixel (deconv) / fully-connected layers all run through this one kernel.
-//   * DP_BF16: v_mfma_f32_16x16x32_bf16 (fp32 accumulate). DP_F32 (parity mode): v_mfma_f32_16x16x4_f32,
-//     bit-exact fp32 FMA chain; same LDS image in bytes, 4 MFMAs per fragment instead of 1.
-//   * workgroup ids are remapped so that consecutive tiles (same pixel rows, neighbouring cout tiles)
-//     run on the same XCD and share its L2.
+// One file, five kernels that share the operand conventions below (DESIGN.md §4.1 has the measurements):
+//   conv_igemm_kernel<BN,NPL>   generic: any Cin multiple of 8 (stem, Cout <= 64, tiny widths), per-lane tap table
+//   conv_ring_kernel<256x256>   8 waves, 4-slot LDS ring of 64-byte K planes, counted vmcnt: the layers that carry the FLOPs
+//   conv_ring_kernel<128x128>   4 waves, same ring: small-M layers
+//   conv_ring2_kernel<256x128>  8 waves, two workgroups per CU: launches whose 256x256 tiling ends in a nearly empty round
+//   conv1x1_stream_kernel<KP>   HBM-bound pointwise layers: resident weight slice, per-wave persistent tiles, no LDS for pixels
+//
+// Shared conventions (wave64):
+//   * the weight tile is the MFMA "A" operand (rows = couts) and the im2col pixel tile the "B" operand (cols = pixels);
+//     a wave always owns 64 couts (four 16x16 tiles) x TP pixel tiles. pack.py permutes the weight rows inside every
+//     64-cout block so that a lane's 16 accumulator rows are two runs of 8 CONSECUTIVE output channels: the epilogue
+//     (store_tile) adds bias / residual, applies ReLU and stores 16-byte pieces straight from registers.
+//   * operands travel global/L2 -> LDS by LDS-DMA (global_load_lds / buffer_load ... lds, 16 B per lane, 1 KiB per wave
+//     instruction, lane-linear destination); zero padding / ragged M / K padding never predicate a load: the generic
+//     kernel reads a 16-byte zero page, the ring kernels an out-of-range buffer offset (hardware returns zeros).
+//   * LDS image: planes of [rows][64 B]; chunk c of row r sits at slot c ^ ((-(r>>2))&3) - applied to the per-lane SOURCE
+//     address of the DMA - and the fragment ds_read_b128 is bank-conflict free.
+//   * the K axis is table driven (ktab: {dy, dx, c0, valid | tap << 8} per 16-byte chunk), so 1x1 / 3x3 / dilated /
+//     7x7-stem / 2x2 sub-pixel (deconv) / fully-connected layers all run through the same kernels; multi-tap layers are
+//     packed channel-block major, taps inner, so consecutive K planes re-read the same pixels shifted by one tap (L2 hits).
+//   * DP_BF16: v_mfma_f32_16x16x32_bf16, DP_F16: v_mfma_f32_16x16x32_f16 (fp32 accumulate). DP_F32 (parity mode):
+//     v_mfma_f32_16x16x4_f32, bit-exact fp32 FMA chain; same LDS image in bytes, 4 MFMAs per fragment instead of 1.
+//   * workgroup ids are remapped so that consecutive tiles (same pixel rows, neighbouring cout tiles) run on the same
+//     XCD and share its L2.
 #include "dp_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -554,7 +563,7 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
 
 template <typename T, int BN>
 int launch_conv_k(const ConvArgs& a, hipStream_t stream) {
-  // K <= 512 bytes-pairs... short-K layers (<= 8 steps of 128 B): 64-byte steps, 32 KiB LDS, 4 workgroups per CU
+  // short-K layers (K <= 8 steps of 128 B): 64-byte steps, 32 KiB LDS, 4 workgroups per CU
   return a.n_ktiles <= 8 ? launch_conv<T, BN, 1>(a, stream) : launch_conv<T, BN, 2>(a, stream);
 }
 

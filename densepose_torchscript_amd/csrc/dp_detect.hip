@@ -504,7 +504,19 @@ struct RoiArgs {
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_kernel(const RoiArgs p) {
   const int img = blockIdx.z, j = blockIdx.y;
-  if (j >= p.counts[img]) return;
+  if (j >= p.counts[img]) {
+    // padded slot of the fixed-size box-head input: zeros (finite) so that the GEMM rows behind it stay finite;
+    // the compact DensePose layout has no padded rows
+    if (!p.compact) {
+      const int C8 = p.C >> 3;
+      const int item0 = blockIdx.x * p.items_per_block;
+      const int item1 = min(p.P * p.P * C8, item0 + p.items_per_block);
+      T* __restrict__ out = reinterpret_cast<T*>(p.out) + ((long long)img * p.max_rois + j) * (long long)p.P * p.P * p.C;
+      const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int item = item0 + threadIdx.x; item < item1; item += blockDim.x) store8(out + (long long)item * 8, z);
+    }
+    return;
+  }
   const float* b = p.boxes + ((long long)img * p.max_rois + j) * 4;
   const float bx1 = b[0], by1 = b[1], bx2 = b[2], by2 = b[3];
   int lvl = 0;

@@ -244,7 +244,7 @@ class Engine:
         P = cfg.box_pool
         maps = [feats[k] for k in ("p2", "p3", "p4", "p5")]
         Cc = maps[0].C
-        pooled = torch.zeros((n * R, P, P, Cc), dtype=self.tdt, device=self.device)  # rows >= count stay 0 (finite)
+        pooled = self._empty((n * R, P, P, Cc))  # rows >= count are zero-filled by the kernel (finite GEMM input)
         self.roi_align(maps, [1.0 / s for s in FPN_STRIDES[:4]], props, counts, n, R, P, cfg.box_sampling, pooled)
         x = Act(pooled.view(n * R, 1, 1, P * P * Cc), n * R, 1, 1, P * P * Cc)
         x = self.conv(Ls["fc1"], x, relu=True)
@@ -482,6 +482,7 @@ class Engine:
         p.scale_xy, p.out_hw, p.out_boxes, p.keep = scale_d.data_ptr(), hw_d.data_ptr(), fin_boxes.data_ptr(), keep.data_ptr()
         L.check(self.lib.dp_postprocess_boxes(C.byref(p), self._stream()), "dp_postprocess_boxes")
         results = []
+        classes = torch.zeros((n, D), dtype=torch.int64, device=self.device)   # single class: person (fast_rcnn.py:128)
         for i in range(n):
             r = int(counts_host[i])
             o = int(offs[i])
@@ -489,7 +490,7 @@ class Engine:
                 "image_size": torch.tensor([orig_hw[i][0], orig_hw[i][1]], dtype=torch.int64),
                 "pred_boxes": fin_boxes[i, :r],
                 "scores": det_scores[i, :r],
-                "pred_classes": torch.zeros((r,), dtype=torch.int64, device=self.device),
+                "pred_classes": classes[i, :r],
                 "pred_densepose_coarse_segm": coarse[o:o + r],
                 "pred_densepose_fine_segm": fine[o:o + r],
                 "pred_densepose_u": u[o:o + r],

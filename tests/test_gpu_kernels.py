@@ -297,10 +297,11 @@ def test_roi_align_matches_oracle(eng, dt, multi):
     boxes[0, 1] = [10, 10, 10, 10]      # zero area
     counts = np.array([50, 33], dtype=np.int32)
     acts = [Act(_nhwc(m, Cc, e.tdt, e.device), n_img, m.shape[2], m.shape[3], Cc) for m in maps]
-    out = torch.zeros((n_img * max_rois, P, P, Cc), dtype=e.tdt, device=e.device)
+    out = torch.full((n_img * max_rois, P, P, Cc), 7.0, dtype=e.tdt, device=e.device)   # garbage: the kernel owns every row
     e.roi_align(acts, scales, torch.from_numpy(boxes).to(e.device), torch.from_numpy(counts).to(e.device), n_img, max_rois, P, 2, out)
     torch.cuda.synchronize()
     got = out.float().cpu().view(n_img, max_rois, P, P, Cc).permute(0, 1, 4, 2, 3)
+    assert float(got[1, counts[1]:].abs().max()) == 0.0   # padded slots of the fixed-size layout are written as zeros
     for i in range(n_img):
         b = torch.from_numpy(boxes[i, : counts[i]])
         rois = torch.cat([torch.zeros((len(b), 1)), b], 1)
