@@ -942,6 +942,8 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   }
   if (big_ok) {
     const long long t256 = ((M + 255) / 256) * (p->Cout / 256);
+    // very long K (box head fc1: 392 planes) amortises the big tile's prologue even on half a chip: 0.267 vs 0.286 ms
+    if (t256 >= 96 && (long long)p->Kpad * es >= 256 * 64) return DP_CONV_RING256;
     if (t256 >= 132) {
       const long long rem = t256 % num_cus();
       if (policy == 1 && t256 < 4ll * num_cus() && rem >= 1 && rem <= num_cus() / 6) return DP_CONV_RING256x128;
