@@ -235,6 +235,31 @@ def test_pipeline_lanes_do_not_change_results():
                     assert torch.equal(a[k].cpu(), b[k].cpu()), (graphs, k)
 
 
+def test_run_cli_frame_sequence_equals_single_frames(tmp_path):
+    """run.py on a [T,H,W,3] .npy (the reference's video loop, run.py:42-57): batched + pipelined == frame by frame."""
+    import subprocess
+    import sys
+    import os
+    from densepose_torchscript_amd import TINY_OPTS
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(21)
+    frames = rng.integers(0, 256, (5, 96, 160, 3), dtype=np.uint8)
+    np.save(tmp_path / "clip.npy", frames)
+    # a tiny yaml-free config: the CLI accepts a variant name only, so the overrides travel through the environment
+    env = dict(os.environ, DP_RUN_OPTS=" ".join(str(o) for o in TINY_OPTS))
+    def run(inp, out):
+        subprocess.check_call([sys.executable, os.path.join(root, "run.py"), "densepose_rcnn_R_50_FPN_s1x", "synthetic:4", str(inp),
+                               "--out", str(out), "--fp32", "--batch", "2", "--min_score", "0.05"], env=env, cwd=root)
+        return np.load(out)
+    seq = run(tmp_path / "clip.npy", tmp_path / "seq.npz")["iuv"]
+    assert seq.shape == (5, 3, 96, 160)
+    for t in (0, 3, 4):
+        np.save(tmp_path / "one.npy", frames[t])
+        one = run(tmp_path / "one.npy", tmp_path / "one.npz")["iuv"]
+        assert np.array_equal(seq[t], one), t
+    assert seq.any()
+
+
 def test_zero_and_many_detections():
     """R = 0 is legal (empty tensors with the right shapes/dtypes); a low threshold gives the DETECTIONS_PER_IMAGE cap."""
     from densepose_torchscript_amd import TINY_OPTS, get_config, make_synthetic_state
