@@ -66,6 +66,35 @@ def test_conv2d_ring_kernels(eng, dt, case, force, monkeypatch):
     test_conv2d_matches_torch(eng, dt, case)
 
 
+def _random_conv_cases(n, seed):
+    """Seeded random layer shapes over everything the engine can emit: ragged M, channel counts that are not tile
+    multiples, stride 2 (pad = (k-1)/2 like every strided conv of the model), dilation, residual / ReLU."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    while len(cases) < n:
+        k = int(rng.choice([1, 3]))
+        s = int(rng.choice([1, 1, 2]))
+        d = int(rng.choice([1, 1, 2])) if (k == 3 and s == 1) else 1
+        cin = int(rng.choice([8, 16, 32, 64, 96, 128, 256]))
+        cout = int(rng.choice([8, 16, 40, 64, 128, 256, 512]))
+        n_img = int(rng.integers(1, 4))
+        h, w = int(rng.integers(5, 41)), int(rng.integers(5, 41))
+        if n_img * h * w * cin * k * k * cout > 3e9:
+            continue
+        cases.append((n_img, cin, h, w, cout, k, s, d * (k - 1) // 2, d, bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
+    return cases
+
+
+@pytest.mark.parametrize("force", [None, "1", "2", "3", "5"])
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_conv2d_random_shapes(eng, dt, force, monkeypatch):
+    """Every kernel class (forced where it is legal for the shape, else the generic fallback) on 24 seeded random shapes."""
+    if force is not None:
+        monkeypatch.setenv("DP_CONV_BIG", force)
+    for case in _random_conv_cases(24, 1234 + (0 if force is None else int(force))):
+        test_conv2d_matches_torch(eng, dt, case)
+
+
 STREAM_CASES = [
     # pointwise, stride 1, Cin*2 B in {128, 256, 512}, Cout % 256 == 0, M >= 4096: the streaming 1x1 kernel (storage-type output)
     (2, 64, 50, 45, 256, 1, 1, 0, 1, True, True),      # res2 conv3 shape class, M = 4500 (ragged last tile)
