@@ -279,7 +279,7 @@ def _random_boxes(rng, n, size=400.0, zero_frac=0.05):
     return b
 
 
-@pytest.mark.parametrize("n_slots,groups", [(1000, 1), (900, 5), (5000, 5), (37, 2)])
+@pytest.mark.parametrize("n_slots,groups", [(1000, 1), (900, 5), (5000, 5), (37, 2), (1, 1), (63, 1), (64, 2), (65, 3), (129, 1), (4097, 5)])
 def test_batched_nms_matches_oracle(eng, n_slots, groups):
     from oracle import ops_ref
     e = eng["fp32"]
@@ -303,6 +303,43 @@ def test_batched_nms_matches_oracle(eng, n_slots, groups):
         assert np.array_equal(oi[i, :cnt].cpu().numpy(), keep)
         assert np.array_equal(ob[i, :cnt].cpu().numpy(), boxes[i][keep])
         assert np.array_equal(os_[i, :cnt].cpu().numpy(), scores[i][keep])
+
+
+@pytest.mark.parametrize("kind", ["all_invalid", "clusters", "identical"])
+def test_batched_nms_degenerate_inputs(eng, kind):
+    """No valid candidate (count 0), dense clusters where most boxes are suppressed by an earlier one of their cluster, and
+    identical boxes with distinct scores (exactly one survives per group)."""
+    from oracle import ops_ref
+    e = eng["fp32"]
+    rng = np.random.default_rng(99)
+    n_img, n = 2, 700
+    if kind == "clusters":
+        centres = rng.random((12, 2)) * 400
+        c = centres[rng.integers(0, 12, n)]
+        wh = 40 + rng.random((n, 2)) * 6
+        xy = c + rng.normal(0, 3, (n, 2))
+        b1 = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        boxes = np.stack([b1, b1[::-1].copy()])
+    elif kind == "identical":
+        boxes = np.tile(np.array([[10, 20, 110, 220]], np.float32), (n_img, n, 1))
+    else:
+        boxes = np.stack([_random_boxes(rng, n) for _ in range(n_img)]).astype(np.float32)
+    scores = np.stack([rng.permutation(n).astype(np.float32) / n for _ in range(n_img)])
+    group = rng.integers(0, 3, (n_img, n)).astype(np.int32)
+    valid = np.zeros((n_img, n), np.int32) if kind == "all_invalid" else np.ones((n_img, n), np.int32)
+    dev = e.device
+    ob, os_, oi, oc = e.nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), torch.from_numpy(group).to(dev),
+                            torch.from_numpy(valid).to(dev), n_img, n, 0.5, 100)
+    torch.cuda.synchronize()
+    for i in range(n_img):
+        cnt = int(oc[i])
+        if kind == "all_invalid":
+            assert cnt == 0
+            continue
+        keep = ops_ref.batched_nms(torch.from_numpy(boxes[i]), torch.from_numpy(scores[i]), torch.from_numpy(group[i]).long(), 0.5).numpy()[:100]
+        assert cnt == len(keep) and np.array_equal(oi[i, :cnt].cpu().numpy(), keep)
+        if kind == "identical":
+            assert cnt == len(np.unique(group[i]))
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
