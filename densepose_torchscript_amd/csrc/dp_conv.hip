@@ -326,8 +326,16 @@ constexpr int kRing = 4;
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+// `planes` whole K planes of this wave's LDS-DMA pieces (pw = 3 or 4 pieces per plane, wave-uniform) may stay in flight
+__device__ __forceinline__ void wait_planes(int planes, int pw) {
+  if (planes <= 0) wait_vmcnt<0>();
+  else if (planes == 1) { if (pw == 4) wait_vmcnt<4>(); else wait_vmcnt<3>(); }
+  else { if (pw == 4) wait_vmcnt<8>(); else wait_vmcnt<6>(); }
 }
 
 template <int I, int N, typename F>
@@ -348,7 +356,12 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
   constexpr int BM = 2 * TP * 16;         // pixels
   constexpr int BN = WC * 64;             // couts
   constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, SLOT = A_PLANE + B_PLANE;
-  static_assert(BM / 16 / NW == 2 && BN / 16 / NW == 2, "each wave stages two 16-row pieces of each operand plane");
+  // staging: a plane has NA = BM/16 pixel pieces and BN/16 weight pieces of 16 rows (1 KiB, one wave instruction each).
+  // Every wave stages two weight pieces and the pixel pieces {wave, wave + NW} that exist: tile heights that are not a
+  // multiple of 16*NW rows (TP = 5, 6, 7) leave some waves with ONE pixel piece, so the per-plane piece count a wave
+  // waits on (pw = 3 or 4) is a wave-uniform runtime value.
+  constexpr int NA = BM / 16;
+  static_assert(BN / 16 / NW == 2 && NA >= NW && NA <= 2 * NW, "two weight pieces and one or two pixel pieces per wave");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -379,14 +392,16 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
   // byte offset of (row, tap (0,0), this lane's chunk) - possibly "virtual" at the border - and a bit mask of the taps
   // that fall inside the image for this row. Per plane the staging then costs one add + one select per load:
   // out-of-image / K-padding chunks get an out-of-range buffer offset, for which the hardware returns zeros.
+  const bool a2 = wave + NW < NA;          // this wave stages a second pixel piece
+  const int pw = a2 ? 4 : 3;               // LDS-DMA pieces per plane of this wave
   int a_boff[2];
   unsigned a_okm[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wave * 32 + i * 16 + srow;
+    const int m = m0 + (wave + i * NW) * 16 + srow;   // pixel piece wave + i*NW
     a_okm[i] = 0u;
     a_boff[i] = 0;
-    if (m < p.M) {
+    if (m < p.M && (i == 0 || a2)) {
       const int n = m / p.HoWo;
       const int rem = m - n * p.HoWo;
       const int ho = rem / p.Wo;
@@ -402,19 +417,22 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
   const int w_boff = ((n0 + wave * 32 + srow) * p.Kpad + scc * CH) * ES;
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
-  unsigned char* const lds_st = smem + wave * 2048;  // this wave's 2 KiB of each plane
+  unsigned char* const lds_sa = smem + wave * 1024;              // pixel piece `wave` (+ NW*1024: piece wave + NW)
+  unsigned char* const lds_sb = smem + A_PLANE + wave * 2048;    // this wave's two weight pieces
 
 #define DP_RING_STAGE(S_IDX, E)                                                                                    \
   {                                                                                                                \
     const int tap_boff = (((E)[0] * p.W + (E)[1]) * p.Cin + (E)[2]) * ES;                                          \
     const unsigned tapbit = ((E)[3] & 1) ? (1u << ((E)[3] >> 8)) : 0u;                                             \
-    unsigned char* dst = lds_st + ((S_IDX) & (kRing - 1)) * SLOT;                                                  \
+    const int slot_ = ((S_IDX) & (kRing - 1)) * SLOT;                                                              \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
-      const int off = (a_okm[i] & tapbit) ? (a_boff[i] + tap_boff) : (int)0x80000000;                              \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(dst + i * 1024), 16, off, 0, 0, 0);               \
+      if (i == 0 || a2) {                                                                                          \
+        const int off = (a_okm[i] & tapbit) ? (a_boff[i] + tap_boff) : (int)0x80000000;                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(lds_sa + slot_ + i * NW * 1024), 16, off, 0, 0, 0); \
+      }                                                                                                            \
     }                                                                                                              \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DP_LDS_PTR(dst + A_PLANE + i * 1024), 16,                     \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DP_LDS_PTR(lds_sb + slot_ + i * 1024), 16,                    \
                                                w_boff + (16 * i * p.Kpad + (S_IDX) * PE) * ES, 0, 0, 0);           \
     }                                                                                                              \
   }
@@ -443,7 +461,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
 #define DP_RING_STEP(S_IDX, FP_CUR, FC_CUR, FP_NXT, FC_NXT)                                                        \
   {                                                                                                                \
     if ((S_IDX) + 1 < ns) {                                                                                        \
-      if ((S_IDX) + 2 < ns) wait_vmcnt<4>(); else wait_vmcnt<0>();   /* only plane S+2 may still be in flight */   \
+      wait_planes((S_IDX) + 2 < ns ? 1 : 0, pw);   /* only plane S+2 may still be in flight */                     \
       __builtin_amdgcn_s_barrier();                                                                                \
       if ((S_IDX) + 3 < ns) {                                                                                      \
         DP_RING_STAGE((S_IDX) + 3, e_nx);                                                                          \
@@ -469,9 +487,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
 
   u32x4 fpA[TP], fcA[TC], fpB[TP], fcB[TC];
   // plane 0 landed once at most planes 1 and 2 (4 LDS-DMAs per plane per wave) are outstanding
-  if (ns > 2) wait_vmcnt<8>();
-  else if (ns > 1) wait_vmcnt<4>();
-  else wait_vmcnt<0>();
+  wait_planes(ns > 2 ? 2 : (ns > 1 ? 1 : 0), pw);
   __builtin_amdgcn_s_barrier();
   DP_RING_READ(0, fpA, fcA);
 
@@ -482,12 +498,12 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
   constexpr int N_MEM = 4 + TC + TP;            // memory instructions per step
   constexpr int N_PAIR = TC * TP;               // fragment pairs (MFMA groups) per step
   auto steady = [&](int S, u32x4 (&fp_cur)[TP], u32x4 (&fc_cur)[TC], u32x4 (&fp_nxt)[TP], u32x4 (&fc_nxt)[TC]) __attribute__((always_inline)) {
-    wait_vmcnt<4>();
+    if (a2) wait_vmcnt<4>(); else wait_vmcnt<3>();   // only plane S+2 may still be in flight
     __builtin_amdgcn_s_barrier();
     const i32x4 e = e_nx;
     const int tap_boff = ((e[0] * p.W + e[1]) * p.Cin + e[2]) * ES;
     const unsigned tapbit = (e[3] & 1) ? (1u << (e[3] >> 8)) : 0u;
-    unsigned char* dst = lds_st + ((S + 3) & (kRing - 1)) * SLOT;
+    const int dslot = ((S + 3) & (kRing - 1)) * SLOT;
     const int rslot = ((S + 1) & (kRing - 1)) * SLOT;
     e_nx = ktab_c[min(S + 4, ns - 1) * 4];
     static_for<0, N_PAIR>([&](auto pi) {
@@ -500,10 +516,12 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
         static_for<m_lo, m_hi>([&](auto mi) {
           constexpr int m = decltype(mi)::value;
           if constexpr (m < 2) {
-            const int off = (a_okm[m] & tapbit) ? (a_boff[m] + tap_boff) : (int)0x80000000;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(dst + m * 1024), 16, off, 0, 0, 0);
+            if (m == 0 || a2) {
+              const int off = (a_okm[m] & tapbit) ? (a_boff[m] + tap_boff) : (int)0x80000000;
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(lds_sa + dslot + m * NW * 1024), 16, off, 0, 0, 0);
+            }
           } else if constexpr (m < 4) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DP_LDS_PTR(dst + A_PLANE + (m - 2) * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DP_LDS_PTR(lds_sb + dslot + (m - 2) * 1024), 16,
                                                      w_boff + (16 * (m - 2) * p.Kpad + (S + 3) * PE) * ES, 0, 0, 0);
           } else if constexpr (m < 4 + TC) {
             fc_nxt[m - 4] = *reinterpret_cast<const u32x4*>(rd_b + rslot + (m - 4) * 16 * 64);
@@ -953,9 +971,41 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   return DP_CONV_RING128;
 }
 
+// Tile height of the 256-cout ring kernel: 32 * TP pixels, TP = 4 .. 8 (template instances). A launch that has fewer
+// 256-row tiles than the chip has CUs leaves CUs idle for its whole duration; it runs on the smallest tile height (>= 160
+// rows) whose tile count still fits ONE round, so that more CUs share the work (50x84-level 3x3: 132 tiles of 256 rows
+// -> 210 of 160 rows, 62 -> 50 us; box head fc1: 128 -> 200 tiles, 274 -> 237 us). Multi-round launches keep 256 rows:
+// measured, a partly filled round runs almost proportionally faster, so shorter tiles only add per-tile overhead there
+// (200x336-level 3x3: 0.672 ms at 256 rows, 0.682 / 0.694 / 0.733 / 0.751 at 224 / 192 / 160 / 128). The per-pixel
+// arithmetic does not depend on the tile a pixel lands in, so results stay bit-identical across batch sizes.
+static int choose_ring256_tp(const dp_conv_params* p, long long M) {
+  const char* fe = getenv("DP_CONV_TP");   // test / calibration knob
+  if (fe) {
+    const int f = atoi(fe);
+    if (f >= 4 && f <= 8) return f;
+  }
+  const long long tn = p->Cout / 256;
+  const long long cus = num_cus();
+  if (((M + 255) / 256) * tn >= cus) return 8;
+  for (int tp = 5; tp < 8; ++tp)
+    if (((M + 32 * tp - 1) / (32 * tp)) * tn <= cus) return tp;
+  return 8;
+}
+
 extern "C" int dp_conv2d_kernel_class(const dp_conv_params* p) {
   if (!p) return -1;
   return choose_conv_kernel(p, (long long)p->N * p->Ho * p->Wo);
+}
+
+extern "C" int dp_conv2d_tile_rows(const dp_conv_params* p) {
+  if (!p) return -1;
+  const long long M = (long long)p->N * p->Ho * p->Wo;
+  switch (choose_conv_kernel(p, M)) {
+    case DP_CONV_RING256: return 32 * choose_ring256_tp(p, M);
+    case DP_CONV_RING256x128: return 256;
+    case DP_CONV_STREAM: return 32;
+    default: return 128;
+  }
 }
 
 // evaluates EXPR with the storage type bound to T and returns its value
@@ -1003,9 +1053,16 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
     DP_BY_DTYPE((launch_conv_stream<T, 8>(a, s)));
   }
   if (kc == DP_CONV_RING256) {
+    const int tp = choose_ring256_tp(p, M);
     a.tiles_n = p->Cout / 256;
-    a.n_tiles = (int)((M + 255) / 256) * a.tiles_n;
-    DP_BY_DTYPE((launch_conv_ring<T, 4, 8>(a, s)));
+    a.n_tiles = (int)((M + 32 * tp - 1) / (32 * tp)) * a.tiles_n;
+    switch (tp) {
+      case 4: { DP_BY_DTYPE((launch_conv_ring<T, 4, 4>(a, s))); }
+      case 5: { DP_BY_DTYPE((launch_conv_ring<T, 4, 5>(a, s))); }
+      case 6: { DP_BY_DTYPE((launch_conv_ring<T, 4, 6>(a, s))); }
+      case 7: { DP_BY_DTYPE((launch_conv_ring<T, 4, 7>(a, s))); }
+      default: { DP_BY_DTYPE((launch_conv_ring<T, 4, 8>(a, s))); }
+    }
   }
   if (kc == DP_CONV_RING256x128) {
     a.tiles_n = (p->Cout + 127) / 128;

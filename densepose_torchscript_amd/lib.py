@@ -104,6 +104,7 @@ SYMBOLS = {
     "dp_preprocess_u8": (c_int, [C.POINTER(PreprocessParams), c_void_p]),
     "dp_conv2d_nhwc": (c_int, [C.POINTER(ConvParams), c_void_p]),
     "dp_conv2d_kernel_class": (c_int, [C.POINTER(ConvParams)]),
+    "dp_conv2d_tile_rows": (c_int, [C.POINTER(ConvParams)]),
     "dp_maxpool3x3s2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_subsample2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_upsample_bilinear2x_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -87,6 +87,9 @@ int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
 /* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile,
  * 3 = 128x128 LDS-ring tile, 4 = 256x128 two-workgroup ring tile, 5 = streaming 1x1 (resident weights) - profiling / roofline bookkeeping only */
 int dp_conv2d_kernel_class(const dp_conv_params* p);
+/* pixel rows of the tile dp_conv2d_nhwc will use for these parameters (the 256-cout ring kernel picks 128 .. 256 rows in
+ * steps of 32 to fit the launch into whole rounds of the chip) - profiling / roofline bookkeeping only */
+int dp_conv2d_tile_rows(const dp_conv_params* p);
 
 /* K3  resnet.py:353  F.max_pool2d(k=3, s=2, p=1), NHWC */
 int dp_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, dp_stream_t stream);

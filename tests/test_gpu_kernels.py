@@ -58,6 +58,15 @@ BIG_CASES = [
 ]
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("tp", ["4", "5", "6", "7"])   # tile heights 128 .. 224 of the 256-cout ring kernel (8 = default, above)
+@pytest.mark.parametrize("case", BIG_CASES[:6])
+def test_conv2d_ring_tile_heights(eng, dt, case, tp, monkeypatch):
+    monkeypatch.setenv("DP_CONV_BIG", "1")
+    monkeypatch.setenv("DP_CONV_TP", tp)
+    test_conv2d_matches_torch(eng, dt, case)
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("force", ["1", "2", "3"])   # 1: 256x256 ring kernel, 2: 128x128 ring kernel, 3: 256x128 two-WG ring kernel
 @pytest.mark.parametrize("case", BIG_CASES)
