@@ -193,6 +193,12 @@ def main():
                 "measured": "K event-instrumented steps on one stream (kernels alone on the chip), %.2f ms/step serialized" % (1e3 * t_ser),
                 "all_conv_classes": {c: {"tflops": round(v[0] / v[1] / 1e12, 2), "calls_per_step": v[2] // args.steps,
                                          "ms_per_step": round(1e3 * v[1] / args.steps, 3)} for c, v in agg.items()}}
+    # the 256-cout ring kernel is one source with one template instance (= one rocprofv3 kernel name) per tile height
+    fam = [v for c, v in agg.items() if c.startswith("conv_ring_kernel<") and c.endswith("x256>")]
+    if fam:
+        ff, ft, fc = sum(v[0] for v in fam), sum(v[1] for v in fam), sum(v[2] for v in fam)
+        roofline["ring256_family"] = {"tflops": round(ff / ft / 1e12, 2), "frac": round(ff / ft / peak, 4), "calls_per_step": fc // args.steps,
+                                      "ms_per_step": round(1e3 * ft / args.steps, 3)}
 
     result = None
     if rank == 0:

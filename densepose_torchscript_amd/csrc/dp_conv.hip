@@ -944,7 +944,7 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   // round is almost empty (p3-level 3x3: 525 tiles), where the 256x128 two-workgroup tile is ~7 % faster; small-M layers
   // (res5, p5, fully-connected: M <= 8400) need the 128x128 tile to occupy the chip at all.
   const char* pe = getenv("DP_CONV_POLICY");  // A/B knob for the calibration runs
-  const int policy = pe ? atoi(pe) : 1;
+  const int policy = pe ? atoi(pe) : 3;
   if (policy == 0) {  // round-1 "a" policy: wave-quantisation estimate only
     const double cus = (double)num_cus();
     const double ts = (double)((M + 127) / 128) * ((p->Cout + 127) / 128);
@@ -964,6 +964,8 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
     if (t256 >= 96 && (long long)p->Kpad * es >= 256 * 64) return DP_CONV_RING256;
     if (t256 >= 132) {
       const long long rem = t256 % num_cus();
+      // policy 1 (round-1 interim): two-workgroup 256x128 tile for an almost empty last round; superseded by the tile
+      // heights of the 256-cout kernel (choose_ring256_tp), kept as an A/B knob
       if (policy == 1 && t256 < 4ll * num_cus() && rem >= 1 && rem <= num_cus() / 6) return DP_CONV_RING256x128;
       return DP_CONV_RING256;
     }
@@ -971,13 +973,17 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   return DP_CONV_RING128;
 }
 
-// Tile height of the 256-cout ring kernel: 32 * TP pixels, TP = 4 .. 8 (template instances). A launch that has fewer
-// 256-row tiles than the chip has CUs leaves CUs idle for its whole duration; it runs on the smallest tile height (>= 160
-// rows) whose tile count still fits ONE round, so that more CUs share the work (50x84-level 3x3: 132 tiles of 256 rows
-// -> 210 of 160 rows, 62 -> 50 us; box head fc1: 128 -> 200 tiles, 274 -> 237 us). Multi-round launches keep 256 rows:
-// measured, a partly filled round runs almost proportionally faster, so shorter tiles only add per-tile overhead there
-// (200x336-level 3x3: 0.672 ms at 256 rows, 0.682 / 0.694 / 0.733 / 0.751 at 224 / 192 / 160 / 128). The per-pixel
-// arithmetic does not depend on the tile a pixel lands in, so results stay bit-identical across batch sizes.
+// Tile height of the 256-cout ring kernel: 32 * TP pixels, TP = 4 .. 8 (template instances). A launch runs in rounds of
+// one workgroup per CU. Measured on MI355X (tools/conv_micro.py with DP_CONV_TP) a tile costs about
+// TP + 1.5 units (TP pixel tiles of MFMA work + a part that does not shrink: weight staging, barriers, prologue) and a
+// partly filled last round costs about half of what the missing tiles would - so
+//     time ~ (ceil(r) + r) / 2 * (TP + 1.5),   r = tiles(TP) / CUs.
+// That one expression reproduces the measured ranking of every shape class of the model: many-round launches keep 256 rows
+// (200x336-level 3x3: 0.672 ms vs 0.682 / 0.694 / 0.733 / 0.751 at 224 / 192 / 160 / 128 rows), launches that would leave
+// CUs idle shrink their tiles (50x84-level 3x3: 132 tiles -> 210 of 160 rows, 62 -> 50 us; fc1: 274 -> 237 us), and a launch
+// whose 256-row tiling ends in an almost empty round (100x168-level 3x3: 525 tiles = 2.05 rounds) takes 192 rows
+// (0.206 ms on the 256x128 two-workgroup kernel -> 0.184 ms). The per-pixel arithmetic does not depend on the tile a pixel
+// lands in, so results stay bit-identical across batch sizes.
 static int choose_ring256_tp(const dp_conv_params* p, long long M) {
   const char* fe = getenv("DP_CONV_TP");   // test / calibration knob
   if (fe) {
@@ -985,11 +991,15 @@ static int choose_ring256_tp(const dp_conv_params* p, long long M) {
     if (f >= 4 && f <= 8) return f;
   }
   const long long tn = p->Cout / 256;
-  const long long cus = num_cus();
-  if (((M + 255) / 256) * tn >= cus) return 8;
-  for (int tp = 5; tp < 8; ++tp)
-    if (((M + 32 * tp - 1) / (32 * tp)) * tn <= cus) return tp;
-  return 8;
+  const double cus = (double)num_cus();
+  int best = 8;
+  double best_cost = 1e30;
+  for (int tp = 8; tp >= 4; --tp) {   // ties go to the taller tile
+    const double r = (double)(((M + 32 * tp - 1) / (32 * tp)) * tn) / cus;
+    const double cost = 0.5 * ((double)(long long)(r + 0.999999) + r) * (tp + 1.5);
+    if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = tp; }
+  }
+  return best;
 }
 
 extern "C" int dp_conv2d_kernel_class(const dp_conv_params* p) {
