@@ -960,15 +960,19 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   }
   if (big_ok) {
     const long long t256 = ((M + 255) / 256) * (p->Cout / 256);
-    // very long K (box head fc1: 392 planes) amortises the big tile's prologue even on half a chip: 0.267 vs 0.286 ms
-    if (t256 >= 96 && (long long)p->Kpad * es >= 256 * 64) return DP_CONV_RING256;
-    if (t256 >= 132) {
-      const long long rem = t256 % num_cus();
-      // policy 1 (round-1 interim): two-workgroup 256x128 tile for an almost empty last round; superseded by the tile
-      // heights of the 256-cout kernel (choose_ring256_tp), kept as an A/B knob
-      if (policy == 1 && t256 < 4ll * num_cus() && rem >= 1 && rem <= num_cus() / 6) return DP_CONV_RING256x128;
-      return DP_CONV_RING256;
+    if (policy == 1) {   // round-1 interim policy, kept as an A/B knob
+      if (t256 >= 96 && (long long)p->Kpad * es >= 256 * 64) return DP_CONV_RING256;
+      if (t256 >= 132) {
+        const long long rem = t256 % num_cus();
+        if (t256 < 4ll * num_cus() && rem >= 1 && rem <= num_cus() / 6) return DP_CONV_RING256x128;
+        return DP_CONV_RING256;
+      }
+      return DP_CONV_RING128;
     }
+    // the 256-cout kernel picks its own tile height (choose_ring256_tp); with 128-row tiles it beats the 128x128 kernel as
+    // soon as it has about half a chip of them (res5 convs, fc2: 5-15 % faster at 132-252 tiles; p5-level 3x3 with 66: slower)
+    const long long t128 = ((M + 127) / 128) * (p->Cout / 256);
+    if (t128 >= 128) return DP_CONV_RING256;
   }
   return DP_CONV_RING128;
 }
