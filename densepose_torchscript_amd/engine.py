@@ -115,8 +115,8 @@ class Engine:
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
             e1.record()
             cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_ring_kernel<256x256>", "conv_ring_kernel<128x128>", "conv_ring2_kernel<256x128>", "conv1x1_stream_kernel")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
-            if cls == "conv_ring_kernel<256x256>":   # one template instance (= one rocprofv3 kernel name) per tile height
-                cls = "conv_ring_kernel<%dx256>" % self.lib.dp_conv2d_tile_rows(C.byref(p))
+            if cls.startswith("conv_ring_kernel<"):   # one template instance (= one rocprofv3 kernel name) per tile height
+                cls = "conv_ring_kernel<%dx%s" % (self.lib.dp_conv2d_tile_rows(C.byref(p)), cls.split("x")[1])
             es = x.t.element_size()
             nbytes = (N * (H * W if s == 1 else Ho * Wo * min(layer.ntaps, s * s)) * x.C * es + layer.weight.numel() * es
                       + N * Ho * Wo * layer.cout * (es_out + (es if residual is not None else 0) // (4 if rshift else 1)))

@@ -19,7 +19,7 @@ def short(name):
         args = [a.strip() for a in m.group(2).split(",")]
         dt = {"unsigned short": "bf16", "_Float16": "f16", "float": "f32"}.get(args[0], args[0])
         if m.group(1) == "conv_ring_kernel":
-            return "conv_ring_kernel<%s>[%s]" % ("%dx256" % (32 * int(args[2])) if args[1] == "4" else "128x128", dt)
+            return "conv_ring_kernel<%dx%d>[%s]" % (32 * int(args[2]), 64 * int(args[1]), dt)
         if m.group(1) == "conv_ring2_kernel":
             return "conv_ring2_kernel<256x128>[%s]" % dt
         if m.group(1) == "conv1x1_stream_kernel":
