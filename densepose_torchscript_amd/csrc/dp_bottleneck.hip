@@ -1,0 +1,362 @@
+// Bottleneck tail in ONE launch for the 64-channel (res2) blocks of the ResNet trunk:
+//
+//     t2  = relu(conv2_3x3(t1) + b2)                      64 -> 64, 9 taps          (resnet.py:195-197)
+//     out = relu(conv3_1x1(t2) + b3 + residual)           64 -> 256                 (resnet.py:199-205)
+//     t1' = relu(conv1'_1x1(out) + b1')                   256 -> 64: conv1 of the NEXT block (resnet.py:192-193), optional
+//
+// (/root/reference/detectron2/modeling/backbone/resnet.py:189-205, FrozenBN folded by pack.py.) Run layer by layer
+// these three are HBM-bound pointwise / short-K launches that move 275 MB tensors five times per block; chained they
+// move them twice (residual in, block output out) plus the 64-channel t1 / t1' side tensors.
+//
+// How the chain works without an LDS round trip: pack.py permutes the weight rows of every 64-cout block so that the 16
+// accumulator values an MFMA lane owns along cout are two runs of 8 CONSECUTIVE output channels of one pixel (dp_conv.hip,
+// store_tile). Converted to the storage type, run h of a 64-cout block IS the B-operand fragment (pixel = lane & 15,
+// 8 channels at K offset 8 * (lane >> 4)) of K step h of the next 1x1 convolution: conv2's accumulators feed conv3 and
+// conv3's epilogue registers feed conv1' directly. The values are rounded to the storage type exactly where the
+// layer-by-layer path stores them, and every accumulation runs in the same K order, so the fused launch is bit-identical
+// to dp_conv2d_nhwc called three times (tests/test_gpu_kernels.py::test_bottleneck_tail_*).
+//
+// Structure (the streaming 1x1 kernel of dp_conv.hip, extended): all three weight matrices (72 + 32 + 32 KiB) are staged
+// into LDS once per workgroup; every wave owns whole 32-pixel tiles (persistent, strided over the pixel range); its
+// conv2 operand fragments (9 taps x 2 channel blocks per pixel tile) and its residual runs are plain 16-byte buffer loads
+// straight into registers, refilled IN PLACE with the wave's next tile right after their last use; zero padding and the
+// ragged tail are out-of-range buffer offsets (loads return 0, stores are dropped). One workgroup of 4 waves per CU.
+#include "dp_common.h"
+#include "dp_mma.h"
+
+namespace {
+
+struct TailArgs {
+  const void* t1;
+  const void* res;
+  void* out;
+  void* t1n;
+  const void* w2;
+  const void* w3;
+  const void* w1n;
+  const i32x4* ktab2;
+  const float* b2;
+  const float* b3;
+  const float* b1n;
+  int N, H, W, M;
+  int kpad2, kpad3, kpad1n;
+  int hi_off, wi_off;
+  unsigned t1_bytes, out_bytes, t1n_bytes;
+};
+
+constexpr int kTailW2 = 18 * 64 * 64;                  // conv2: 18 K planes x 64 couts x 64 B
+constexpr int kTailW3 = 2 * 256 * 64;                  // conv3: 2 planes x 256 couts
+constexpr int kTailW1 = 8 * 64 * 64;                   // conv1': 8 planes x 64 couts
+constexpr int kTailBias = (64 + 256 + 64) * 4;
+constexpr int kTailLds = kTailW2 + kTailW3 + kTailW1 + kTailBias;
+
+template <typename T, bool HAS_NEXT>
+__global__ __launch_bounds__(256, 1) void bottleneck_tail64_kernel(const TailArgs p) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int TP = 2;                  // 32 pixels per wave tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const w2_s = smem;
+  unsigned char* const w3_s = smem + kTailW2;
+  unsigned char* const w1_s = smem + kTailW2 + kTailW3;
+  float* const b2_s = reinterpret_cast<float*>(smem + kTailW2 + kTailW3 + kTailW1);
+  float* const b3_s = b2_s + 64;
+  float* const b1_s = b3_s + 256;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- weights -> LDS, once: piece = (K plane, 16-row group), 1 KiB per wave instruction; the 16-byte chunk c of row r
+  //      lands at slot c ^ swz(r) (swizzle applied to the per-lane SOURCE address, the LDS-DMA destination is lane-linear)
+  {
+    const int srow = lane >> 2;
+    const int scc = (lane & 3) ^ swz(srow);
+    const T* __restrict__ w2 = reinterpret_cast<const T*>(p.w2) + (long long)srow * p.kpad2 + scc * 8;
+    for (int piece = wave; piece < 18 * 4; piece += 4) {
+      const int pl = piece >> 2, rg = piece & 3;
+      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w2 + (long long)(rg * 16) * p.kpad2 + pl * 32),
+                                       DP_LDS_PTR(w2_s + pl * 4096 + rg * 1024), 16, 0, 0);
+    }
+    const T* __restrict__ w3 = reinterpret_cast<const T*>(p.w3) + (long long)srow * p.kpad3 + scc * 8;
+    for (int piece = wave; piece < 2 * 16; piece += 4) {
+      const int pl = piece >> 4, rg = piece & 15;
+      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w3 + (long long)(rg * 16) * p.kpad3 + pl * 32),
+                                       DP_LDS_PTR(w3_s + pl * 16384 + rg * 1024), 16, 0, 0);
+    }
+    if (HAS_NEXT) {
+      const T* __restrict__ w1 = reinterpret_cast<const T*>(p.w1n) + (long long)srow * p.kpad1n + scc * 8;
+      for (int piece = wave; piece < 8 * 4; piece += 4) {
+        const int pl = piece >> 2, rg = piece & 3;
+        __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w1 + (long long)(rg * 16) * p.kpad1n + pl * 32),
+                                         DP_LDS_PTR(w1_s + pl * 4096 + rg * 1024), 16, 0, 0);
+      }
+    }
+    if (tid < 64) b2_s[tid] = p.b2[tid];
+    b3_s[tid] = p.b3[tid];
+    if (HAS_NEXT && tid < 64) b1_s[tid] = p.b1n[tid];
+  }
+  __syncthreads();  // (vmcnt(0) + barrier)
+
+  const int fr = lane & 15;
+  const int fq = lane >> 4;
+  const int rd = fr * 64 + ((fq ^ swz(fr)) << 4);   // fragment read offset inside a 16-row group of a plane
+  const int n_wt = (p.M + 31) >> 5;
+  const int wt_step = gridDim.x * 4;
+  int wt = blockIdx.x * 4 + wave;
+  if (wt >= n_wt) return;
+
+  // the 9 taps of conv2 (wave-uniform): pixel displacement and its byte offset in the 128-byte-per-pixel t1 tensor
+  const __attribute__((address_space(4))) i32x4* ktab_c = (const __attribute__((address_space(4))) i32x4*)p.ktab2;
+  int tdy[9], tdx[9], toff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const i32x4 e = ktab_c[t * 4];   // planes 0..8 of the channel-block-major packing enumerate the taps
+    tdy[t] = e[0] + p.hi_off;
+    tdx[t] = e[1] + p.wi_off;
+    toff[t] = (tdy[t] * p.W + tdx[t]) * 128;
+  }
+  const int HW = p.H * p.W;
+
+  const __amdgpu_buffer_rsrc_t rs_t1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.t1), 0, p.t1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_t1n = __builtin_amdgcn_make_buffer_rsrc(HAS_NEXT ? p.t1n : p.out, 0, HAS_NEXT ? p.t1n_bytes : 0u, 0x00020000);
+
+  // per-lane view of a wave tile: pixel m of each of the two 16-pixel MFMA tiles, the bit mask of the taps that fall inside
+  // the image for that pixel, and its byte offset (chunk fq) in t1. Pixels >= M get an empty mask and out-of-range offsets.
+  auto tile_geom = [&](int tile, int (&m)[TP], unsigned (&okm)[TP]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+      m[j] = tile * 32 + j * 16 + fr;
+      okm[j] = 0u;
+      if (m[j] < p.M) {
+        const int n = m[j] / HW;
+        const int rem = m[j] - n * HW;
+        const int ho = rem / p.W;
+        const int wo = rem - ho * p.W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          if ((unsigned)(ho + tdy[t]) < (unsigned)p.H && (unsigned)(wo + tdx[t]) < (unsigned)p.W) okm[j] |= 1u << t;
+      }
+    }
+  };
+  auto tap_load = [&](int s, int mj, unsigned okm) __attribute__((always_inline)) -> u32x4 {
+    const int t = s % 9, cb = s / 9;   // K plane s = channel block cb, tap t
+    const int off = ((okm >> t) & 1u) ? (mj * 128 + fq * 16 + toff[t] + cb * 64) : (int)0x80000000;
+    return __builtin_amdgcn_raw_buffer_load_b128(rs_t1, off, 0, 0);
+  };
+
+  u32x4 a[18][TP];      // conv2 operand fragments of the CURRENT tile (refilled in place with the next one)
+  u32x4 r[TP][8];       // residual runs of the current tile
+  int m_cur[TP], m_nxt[TP];
+  unsigned ok_cur[TP], ok_nxt[TP];
+  tile_geom(wt, m_cur, ok_cur);
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+#pragma unroll
+    for (int s = 0; s < 18; ++s) a[s][j] = tap_load(s, m_cur[j], ok_cur[j]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, m_cur[j] * 512 + q * 64 + fq * 16, 0, 0);
+  }
+
+  for (; wt < n_wt; wt += wt_step) {
+    tile_geom(wt + wt_step, m_nxt, ok_nxt);   // past the end: every pixel >= M
+
+    // ---- conv2: 18 K planes, A = W2 fragments from LDS, B = tap fragments in registers
+    f32x4 acc2[4][TP];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < TP; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+      u32x4 wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const u32x4*>(w2_s + s * 4096 + i * 1024 + rd);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) Mma<T>::run(wf[i], a[s][j], acc2[i][j]);
+#pragma unroll
+      for (int j = 0; j < TP; ++j) a[s][j] = tap_load(s, m_nxt[j], ok_nxt[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- t2 = relu(acc2 + b2), rounded to the storage type: run h of pixel tile j is conv3's B fragment of K plane h
+    u32x4 tf[2][TP];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(b2_s + h * 32 + fq * 8);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(b2_s + h * 32 + fq * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < TP; ++j) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[k] = fmaxf(acc2[2 * h][j][k] + b0[k], 0.f);
+          v[4 + k] = fmaxf(acc2[2 * h + 1][j][k] + b1[k], 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tf[h][j][k] = Elem<T>::pack2(v[2 * k], v[2 * k + 1]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- conv3 (four 64-cout blocks) + bias + residual + ReLU -> out; the packed runs stay in registers for conv1'
+    u32x4 xf[8][TP];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      f32x4 acc3[4][TP];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        u32x4 wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const u32x4*>(w3_s + s * 16384 + (b * 64 + i * 16) * 64 + rd);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < TP; ++j) Mma<T>::run(wf[i], tf[s][j], acc3[i][j]);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int q = 2 * b + h;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(b3_s + q * 32 + fq * 8);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(b3_s + q * 32 + fq * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[k] = acc3[2 * h][j][k] + b0[k];
+            v[4 + k] = acc3[2 * h + 1][j][k] + b1[k];
+          }
+          const u32x4 rv = r[j][q];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[2 * k] += Elem<T>::unpack(rv[k] & 0xffffu);
+            v[2 * k + 1] += Elem<T>::unpack(rv[k] >> 16);
+          }
+          r[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, m_nxt[j] * 512 + q * 64 + fq * 16, 0, 0);
+          u32x4 pk;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) pk[k] = Elem<T>::pack2(fmaxf(v[2 * k], 0.f), fmaxf(v[2 * k + 1], 0.f));
+          __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, m_cur[j] * 512 + q * 64 + fq * 16, 0, 0);
+          xf[q][j] = pk;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- conv1' of the next block: K = the 256 channels just produced (8 planes = the 8 runs above)
+    if (HAS_NEXT) {
+      f32x4 acc1[4][TP];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        u32x4 wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const u32x4*>(w1_s + q * 4096 + i * 1024 + rd);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < TP; ++j) Mma<T>::run(wf[i], xf[q][j], acc1[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(b1_s + h * 32 + fq * 8);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(b1_s + h * 32 + fq * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[k] = fmaxf(acc1[2 * h][j][k] + b0[k], 0.f);
+            v[4 + k] = fmaxf(acc1[2 * h + 1][j][k] + b1[k], 0.f);
+          }
+          u32x4 pk;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) pk[k] = Elem<T>::pack2(v[2 * k], v[2 * k + 1]);
+          __builtin_amdgcn_raw_buffer_store_b128(pk, rs_t1n, m_cur[j] * 128 + h * 64 + fq * 16, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < TP; ++j) { m_cur[j] = m_nxt[j]; ok_cur[j] = ok_nxt[j]; }
+  }
+}
+
+static int tail_num_cus() {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    return prop.multiProcessorCount;
+  return 256;
+}
+
+template <typename T, bool HAS_NEXT>
+int launch_tail(const TailArgs& a, hipStream_t stream) {
+  static bool attr_set = false;
+  static int cus = 0;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_tail64_kernel<T, HAS_NEXT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds);
+    cus = tail_num_cus();
+    attr_set = true;
+  }
+  const int n_wt = (a.M + 31) / 32;
+  int gx = cus;
+  if (gx > (n_wt + 3) / 4) gx = (n_wt + 3) / 4;
+  hipLaunchKernelGGL((bottleneck_tail64_kernel<T, HAS_NEXT>), dim3(gx), dim3(256), kTailLds, stream, a);
+  return dp_check_launch("bottleneck_tail64_kernel");
+}
+
+}  // namespace
+
+// 1 when dp_bottleneck_tail_nhwc has a fused kernel for these parameters (else the caller runs the three layers through
+// dp_conv2d_nhwc); the checks are the ones dp_bottleneck_tail_nhwc enforces.
+static const char* tail_unsupported(const dp_bottleneck_params* p) {
+  if (p->dtype != DP_BF16 && p->dtype != DP_F16) return "16-bit storage only";
+  if (p->Cmid != 64 || p->Cout != 256) return "only the 64 -> 64 -> 256 (res2) shape is fused";
+  if (p->ntaps2 != 9 || p->Kpad2 != 576 || p->Kpad3 != 64) return "conv2 must be 3x3 over 64 channels (Kpad 576), conv3 1x1 (Kpad 64)";
+  if (p->next_t1 && (p->Cmid_next != 64 || p->Kpad1n != 256)) return "next conv1 must be 256 -> 64 (Kpad 256)";
+  const long long M = (long long)p->N * p->H * p->W;
+  // 32-bit buffer offsets; pixels up to one grid stride of tiles past the end are addressed before the range check drops them
+  if ((M + (1ll << 16)) * 512 >= (1ll << 31)) return "tensor too large for 32-bit buffer offsets (split the batch)";
+  return nullptr;
+}
+
+extern "C" int dp_bottleneck_tail_supported(const dp_bottleneck_params* p) {
+  if (!p) return 0;
+  return tail_unsupported(p) == nullptr ? 1 : 0;
+}
+
+extern "C" int dp_bottleneck_tail_nhwc(const dp_bottleneck_params* p, dp_stream_t stream) {
+  DP_REQUIRE(p != nullptr, "dp_bottleneck_tail_nhwc: null params");
+  DP_REQUIRE(p->N >= 0 && p->H > 0 && p->W > 0, "dp_bottleneck_tail_nhwc: bad spatial shape");
+  const char* why = tail_unsupported(p);
+  if (why) return dp_fail(DP_ERR_UNSUPPORTED, "dp_bottleneck_tail_nhwc: %s", why);
+  const long long M = (long long)p->N * p->H * p->W;
+  if (M == 0) return DP_OK;
+  DP_REQUIRE(p->t1 && p->residual && p->out && p->w2 && p->w3 && p->ktab2 && p->b2 && p->b3, "dp_bottleneck_tail_nhwc: null pointer");
+  DP_REQUIRE(!p->next_t1 || (p->w1n && p->b1n), "dp_bottleneck_tail_nhwc: next_t1 given without its weights");
+  TailArgs a;
+  a.t1 = p->t1; a.res = p->residual; a.out = p->out; a.t1n = p->next_t1;
+  a.w2 = p->w2; a.w3 = p->w3; a.w1n = p->w1n; a.ktab2 = reinterpret_cast<const i32x4*>(p->ktab2);
+  a.b2 = p->b2; a.b3 = p->b3; a.b1n = p->b1n;
+  a.N = p->N; a.H = p->H; a.W = p->W; a.M = (int)M;
+  a.kpad2 = p->Kpad2; a.kpad3 = p->Kpad3; a.kpad1n = p->Kpad1n;
+  a.hi_off = p->hi_off2; a.wi_off = p->wi_off2;
+  a.t1_bytes = (unsigned)(M * 128); a.out_bytes = (unsigned)(M * 512); a.t1n_bytes = (unsigned)(M * 128);
+  hipStream_t s = as_stream(stream);
+  if (p->dtype == DP_BF16) return p->next_t1 ? launch_tail<uint16_t, true>(a, s) : launch_tail<uint16_t, false>(a, s);
+  return p->next_t1 ? launch_tail<f16_t, true>(a, s) : launch_tail<f16_t, false>(a, s);
+}

@@ -30,14 +30,11 @@
 //   * workgroup ids are remapped so that consecutive tiles (same pixel rows, neighbouring cout tiles) run on the same
 //     XCD and share its L2.
 #include "dp_common.h"
+#include "dp_mma.h"
 #include <stdlib.h>
 #include <type_traits>
 
 namespace {
-
-// native clang vectors (HIP's uint4/int4 are structs; arrays of them ended up in scratch memory)
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBM = 128;       // pixels per workgroup
 constexpr int kKB = 128;       // bytes of K per step
@@ -57,38 +54,9 @@ struct ConvArgs {
   int ntaps, out_linear, res_linear;
 };
 
-__device__ __forceinline__ int swz(int r) { return (-(r >> 2)) & 3; }
-
 // 16 zero bytes in global memory: out-of-image / K-padding chunks are loaded from here, so every staging load is
 // unconditional (a predicated load makes hipcc branch around it and wait vmcnt(0) per load: serialised round trips).
 __device__ u32x4 g_zero16 = {0u, 0u, 0u, 0u};
-
-template <typename T>
-struct Mma;
-template <>
-struct Mma<uint16_t> {
-  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  }
-};
-template <>
-struct Mma<f16_t> {
-  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  }
-};
-template <>
-struct Mma<float> {
-  __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
-    // whole-vector bit_cast, then index: bit_cast of a single ext-vector element (a.y ...) silently read element 0
-    const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], c, 0, 0, 0);
-  }
-};
-
 
 // ---- register epilogue ----------------------------------------------------------------------------------------
 // Every kernel below gives a wave 64 couts (four 16x16 MFMA tiles i = 0..3 along cout, weights as the A operand) x TP
@@ -158,9 +126,6 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, const f32x4 (&acc)
     }
   }
 }
-
-#define DP_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
-#define DP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 // NPL = 64-byte K planes per pipeline stage: 2 (128-byte K step, 64 KiB LDS, 2 workgroups/CU) for compute-heavy layers,
 // 1 (64-byte K step, 32 KiB LDS, 4 workgroups/CU) for the short-K, HBM-bound 1x1 layers where resident workgroups

@@ -5,6 +5,7 @@ by stage; every arithmetic step is a call into libdensepose_hip.so (no torch com
 torch only owns device memory and the stream). Batch semantics follow SURVEY Q6: a batch of N frames
 equals N independent single-image calls (per-image top-k / NMS / padding).
 """
+import contextlib
 import ctypes as C
 import math
 
@@ -51,18 +52,23 @@ class Engine:
                 h = r * w
                 rows.append([np.float32(-w / 2.0), np.float32(-h / 2.0), np.float32(w / 2.0), np.float32(h / 2.0)])
             self.cell_anchors.append(rows)
-        self.stage_ms = {}
+        self.trace = None   # trace.StageTrace: optional per-stage event timers / roctx ranges (off by default)
         self.keep_intermediates = False
         self.inter = {}
         self.flops_last = 0
         self.prof = None  # list of (kernel class, algorithmic flops, start event, end event) when profiling
         self.use_graphs = False
+        self.fuse_bottleneck = True   # res2 blocks: conv2 -> conv3 -> next conv1 in one launch (bottleneck_tail)
         self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
         self._side_streams = {}
         self._graphs = {}
         self._pinned = {}
 
     # ------------------------------------------------------------------ helpers
+    def _stage(self, name):
+        """bracket of one stage of the path for the optional tracer (trace.py); a no-op context when tracing is off"""
+        return self.trace.stage(name, self) if self.trace is not None else contextlib.nullcontext()
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -126,6 +132,52 @@ class Engine:
         self.flops_last += flops
         return Act(out, N, Ho, Wo, cs)
 
+    def bottleneck_tail(self, l2, l3, l1n, t1, residual):
+        """conv2 -> conv3 (+ residual, ReLU) -> conv1 of the next block in one launch (dp_bottleneck_tail_nhwc).
+        Returns (block output, next block's conv1 output or None), or None when the library has no fused kernel for the
+        shape (fp32 parity mode, every stage but res2, tiny widths): the caller then runs the layers one by one."""
+        p = L.BottleneckParams()
+        N, H, W = t1.N, t1.H, t1.W
+        p.N, p.H, p.W = N, H, W
+        p.Cmid, p.Cout, p.Cmid_next = l2.cout, l3.cout, (l1n.cout if l1n is not None else 0)
+        p.Kpad2, p.Kpad3, p.Kpad1n = l2.kpad, l3.kpad, (l1n.kpad if l1n is not None else 0)
+        p.ntaps2, p.hi_off2, p.wi_off2, p.dtype = l2.ntaps, l2.hi_off, l2.wi_off, self.dt
+        if (l2.stride != 1 or l3.stride != 1 or l3.ntaps != 1 or t1.C != l2.cin or l2.cout != l3.cin or residual.C != l3.cout
+                or (l1n is not None and (l1n.stride != 1 or l1n.ntaps != 1 or l1n.cin != l3.cout))):
+            return None
+        # 32-bit buffer offsets inside the kernel: large batches go image chunk by image chunk
+        per = max(1, ((1 << 31) // (l3.cout * 2) - (1 << 17)) // (H * W))
+        p.N = min(N, per)
+        p.next_t1 = 1 if l1n is not None else None   # placeholder: only NULL / non-NULL matters to the support query
+        if not self.lib.dp_bottleneck_tail_supported(C.byref(p)):
+            return None
+        out = self._empty((N, H, W, l3.cout))
+        t1n = self._empty((N, H, W, l1n.cout)) if l1n is not None else None
+        p.w2, p.w3, p.ktab2, p.b2, p.b3 = l2.weight.data_ptr(), l3.weight.data_ptr(), l2.ktab.data_ptr(), l2.bias.data_ptr(), l3.bias.data_ptr()
+        if l1n is not None:
+            p.w1n, p.b1n = l1n.weight.data_ptr(), l1n.bias.data_ptr()
+        es = out.element_size()
+        macs = l2.macs_per_pixel + l3.macs_per_pixel + (l1n.macs_per_pixel if l1n is not None else 0)
+        flops = 2 * macs * N * H * W
+        prof = self.prof is not None and N * H * W > 0
+        if prof:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+        for n0 in range(0, N, per):
+            n = min(per, N - n0)
+            px = n0 * H * W
+            p.N = n
+            p.t1, p.residual, p.out = t1.t.data_ptr() + px * t1.C * es, residual.t.data_ptr() + px * residual.C * es, out.data_ptr() + px * l3.cout * es
+            p.next_t1 = (t1n.data_ptr() + px * l1n.cout * es) if l1n is not None else None
+            L.check(self.lib.dp_bottleneck_tail_nhwc(C.byref(p), self._stream()), "dp_bottleneck_tail_nhwc[%s]" % l2.name)
+        if prof:
+            e1.record(torch.cuda.current_stream(self.device))
+            nbytes = N * H * W * es * (t1.C + 2 * l3.cout + (l1n.cout if l1n is not None else 0)) + (l2.weight.numel() + l3.weight.numel()) * es
+            self.prof.append(("bottleneck_tail64_kernel", flops, e0, e1, "%s+conv3%s %dx%dx%d->%d" % (
+                l2.name, "+next conv1" if l1n is not None else "", H, W, t1.C, l3.cout), nbytes))
+        self.flops_last += flops
+        return Act(out, N, H, W, l3.cout), (Act(t1n, N, H, W, l1n.cout) if l1n is not None else None)
+
     # ------------------------------------------------------------------ stages
     def preprocess(self, images_u8, Hp, Wp):
         n, _, h, w = images_u8.shape
@@ -143,30 +195,43 @@ class Engine:
         Ls = self.model.layers
         cfg = self.cfg
         bu = "backbone.bottom_up."
-        x = self.conv(Ls["stem"], x, relu=True)
-        Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
-        pooled = self._empty((x.N, Ho, Wo, x.C))
-        L.check(self.lib.dp_maxpool3x3s2_nhwc(x.t.data_ptr(), pooled.data_ptr(), x.N, x.H, x.W, x.C, self.dt, self._stream()), "maxpool")
-        x = Act(pooled, x.N, Ho, Wo, x.C)
+        with self._stage("backbone.stem"):
+            x = self.conv(Ls["stem"], x, relu=True)
+            Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
+            pooled = self._empty((x.N, Ho, Wo, x.C))
+            L.check(self.lib.dp_maxpool3x3s2_nhwc(x.t.data_ptr(), pooled.data_ptr(), x.N, x.H, x.W, x.C, self.dt, self._stream()), "maxpool")
+            x = Act(pooled, x.N, Ho, Wo, x.C)
         res = {}
-        for stage, b, cin, cmid, cout, stride, sc in resnet_blocks(cfg):
+        blocks = list(resnet_blocks(cfg))
+        t_next = None   # conv1 output of the coming block, when the previous block's fused tail already produced it
+        for bi, (stage, b, cin, cmid, cout, stride, sc) in enumerate(blocks):
             p = "%s%s.%d." % (bu, stage, b)
-            shortcut = self.conv(Ls[p + "shortcut"], x) if sc else x
-            t = self.conv(Ls[p + "conv1"], x, relu=True)
-            t = self.conv(Ls[p + "conv2"], t, relu=True)
-            x = self.conv(Ls[p + "conv3"], t, relu=True, residual=shortcut)
+            with self._stage("backbone." + stage):
+                shortcut = self.conv(Ls[p + "shortcut"], x) if sc else x
+                t = t_next if t_next is not None else self.conv(Ls[p + "conv1"], x, relu=True)
+                t_next = None
+                # conv1 of the next block of the SAME stage (stride 1, reads this block's output) rides in the fused tail
+                nxt = blocks[bi + 1] if bi + 1 < len(blocks) and blocks[bi + 1][0] == stage else None
+                l1n = Ls["%s%s.%d.conv1" % (bu, nxt[0], nxt[1])] if nxt is not None else None
+                fused = self.bottleneck_tail(Ls[p + "conv2"], Ls[p + "conv3"], l1n, t, shortcut) if self.fuse_bottleneck else None
+                if fused is not None:
+                    x, t_next = fused
+                else:
+                    t = self.conv(Ls[p + "conv2"], t, relu=True)
+                    x = self.conv(Ls[p + "conv3"], t, relu=True, residual=shortcut)
             res[stage] = x
         feats = {}
-        prev = self.conv(Ls["fpn_lateral5"], res["res5"])
-        feats["p5"] = self.conv(Ls["fpn_output5"], prev)
-        for lvl in (4, 3, 2):
-            prev = self.conv(Ls["fpn_lateral%d" % lvl], res["res%d" % lvl], residual=prev, rshift=1)  # + nearest x2 of top-down
-            feats["p%d" % lvl] = self.conv(Ls["fpn_output%d" % lvl], prev)
-        p5 = feats["p5"]
-        H6, W6 = (p5.H - 1) // 2 + 1, (p5.W - 1) // 2 + 1
-        p6 = self._empty((p5.N, H6, W6, p5.C))
-        L.check(self.lib.dp_subsample2_nhwc(p5.t.data_ptr(), p6.data_ptr(), p5.N, p5.H, p5.W, p5.C, self.dt, self._stream()), "subsample2")
-        feats["p6"] = Act(p6, p5.N, H6, W6, p5.C)
+        with self._stage("backbone.fpn"):
+            prev = self.conv(Ls["fpn_lateral5"], res["res5"])
+            feats["p5"] = self.conv(Ls["fpn_output5"], prev)
+            for lvl in (4, 3, 2):
+                prev = self.conv(Ls["fpn_lateral%d" % lvl], res["res%d" % lvl], residual=prev, rshift=1)  # + nearest x2 of top-down
+                feats["p%d" % lvl] = self.conv(Ls["fpn_output%d" % lvl], prev)
+            p5 = feats["p5"]
+            H6, W6 = (p5.H - 1) // 2 + 1, (p5.W - 1) // 2 + 1
+            p6 = self._empty((p5.N, H6, W6, p5.C))
+            L.check(self.lib.dp_subsample2_nhwc(p5.t.data_ptr(), p6.data_ptr(), p5.N, p5.H, p5.W, p5.C, self.dt, self._stream()), "subsample2")
+            feats["p6"] = Act(p6, p5.N, H6, W6, p5.C)
         return feats
 
     def rpn(self, feats, Hp, Wp):
@@ -359,7 +424,9 @@ class Engine:
         offs[1:] = np.cumsum(counts_host)[:-1]
         offsets = torch.from_numpy(offs).to(self.device, non_blocking=True)
         if cfg.dp_decoder_on:
-            dec = dec if dec is not None else self.decoder(feats)
+            if dec is None:
+                with self._stage("decoder"):
+                    dec = self.decoder(feats)
             maps, scales = [dec], [1.0 / 4]
             if self.keep_intermediates:
                 self.inter["decoder_out"] = dec
@@ -369,20 +436,22 @@ class Engine:
         Cc = maps[0].C
         pooled = self._empty((max(R, 1), P, P, Cc))
         if R > 0:
-            self.roi_align(maps, scales, det_boxes, det_counts_dev, n, D, P, cfg.dp_sampling, pooled, compact=True, offsets=offsets)
+            with self._stage("dp_pool"):
+                self.roi_align(maps, scales, det_boxes, det_counts_dev, n, D, P, cfg.dp_sampling, pooled, compact=True, offsets=offsets)
         x = Act(pooled[:R], R, P, P, Cc)
         if R == 0:
             S = 4 * P
             z = lambda c: torch.zeros((0, c, S, S), dtype=torch.float32, device=self.device)  # noqa: E731
             return z(cfg.dp_coarse_ch), z(cfg.dp_patches + 1), z(cfg.dp_patches + 1), z(cfg.dp_patches + 1), offs
-        head = self.dp_head(x)
+        with self._stage("dp_head"):
+            head = self.dp_head(x)
         if self.keep_intermediates:
             self.inter["dp_pooled"] = x
             self.inter["dp_head_out"] = head
-        coarse, fine, u, v = self.dp_predictor(head)
+        with self._stage("dp_predictor"):
+            coarse, fine, u, v = self.dp_predictor(head)
         return coarse, fine, u, v, offs
 
-    # ------------------------------------------------------------------ whole path for a batch of equal-size frames
     # ------------------------------------------------------------------ whole path for a batch of equal-size frames
     def _phase_a(self, images_u8, given_boxes=None):
         """preprocess -> backbone -> RPN -> box head -> detection select (everything whose launch sizes are static)."""
@@ -390,7 +459,8 @@ class Engine:
         images_u8 = images_u8.contiguous()
         n, _, h, w = images_u8.shape
         Hp, Wp = round_up(h, 32), round_up(w, 32)
-        x = self.preprocess(images_u8, Hp, Wp)
+        with self._stage("preprocess"):
+            x = self.preprocess(images_u8, Hp, Wp)
         feats = self.backbone(x)
         if self.keep_intermediates:
             self.inter.update(feats)
@@ -403,13 +473,15 @@ class Engine:
             if side is None:
                 side = self._side_streams[cur.cuda_stream] = torch.cuda.Stream(device=self.device)
             side.wait_stream(cur)
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), self._stage("decoder"):
                 dec = self.decoder(feats)
         if given_boxes is None:
-            props, prop_scores, prop_counts = self.rpn(feats, Hp, Wp)
+            with self._stage("rpn"):
+                props, prop_scores, prop_counts = self.rpn(feats, Hp, Wp)
             if self.keep_intermediates:
                 self.inter["proposals"] = (props, prop_scores, prop_counts)
-            det_boxes, det_scores, det_counts = self.box_branch(feats, props, prop_counts)
+            with self._stage("box_head"):
+                det_boxes, det_scores, det_counts = self.box_branch(feats, props, prop_counts)
         else:
             det_boxes, det_scores, det_counts = given_boxes
         if side is not None:
@@ -429,7 +501,7 @@ class Engine:
         (sub-batch shape, stream slot) is captured once into a HIP graph and replayed: the ~200 kernel launches of the
         static part cost one graph launch on the host instead of ~200 x (ctypes call + hipLaunchKernel)."""
         n = images_u8.shape[0]
-        graphable = self.use_graphs and given_boxes is None and not self.keep_intermediates and self.prof is None
+        graphable = self.use_graphs and given_boxes is None and not self.keep_intermediates and self.prof is None and self.trace is None
         if not graphable:
             st = self._phase_a(images_u8, given_boxes)
             pinned = self._pinned_counts(("eager", slot), n)

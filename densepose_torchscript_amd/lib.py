@@ -37,6 +37,17 @@ class ConvParams(C.Structure):
                 ("hi_off", c_i32), ("wi_off", c_i32)]
 
 
+class BottleneckParams(C.Structure):
+    _fields_ = [("t1", c_void_p), ("residual", c_void_p), ("out", c_void_p), ("next_t1", c_void_p),
+                ("w2", c_void_p), ("w3", c_void_p), ("w1n", c_void_p), ("ktab2", c_void_p),
+                ("b2", c_void_p), ("b3", c_void_p), ("b1n", c_void_p),
+                ("N", c_i32), ("H", c_i32), ("W", c_i32),
+                ("Cmid", c_i32), ("Cout", c_i32), ("Cmid_next", c_i32),
+                ("Kpad2", c_i32), ("Kpad3", c_i32), ("Kpad1n", c_i32),
+                ("ntaps2", c_i32), ("hi_off2", c_i32), ("wi_off2", c_i32),
+                ("dtype", c_i32)]
+
+
 class RpnLevelParams(C.Structure):
     _fields_ = [("head", c_void_p),
                 ("n_img", c_i32), ("Hi", c_i32), ("Wi", c_i32), ("A", c_i32), ("head_c", c_i32),
@@ -105,6 +116,8 @@ SYMBOLS = {
     "dp_conv2d_nhwc": (c_int, [C.POINTER(ConvParams), c_void_p]),
     "dp_conv2d_kernel_class": (c_int, [C.POINTER(ConvParams)]),
     "dp_conv2d_tile_rows": (c_int, [C.POINTER(ConvParams)]),
+    "dp_bottleneck_tail_supported": (c_int, [C.POINTER(BottleneckParams)]),
+    "dp_bottleneck_tail_nhwc": (c_int, [C.POINTER(BottleneckParams), c_void_p]),
     "dp_maxpool3x3s2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_subsample2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_upsample_bilinear2x_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

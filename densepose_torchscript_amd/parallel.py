@@ -3,6 +3,10 @@ broadcast once from rank 0 over RCCL/xGMI, then every rank runs the whole path o
 collective in the hot loop. (The reference has no distributed code at all; frames are its only independent unit.)
 """
 import os
+import socket
+import subprocess
+import sys
+import time
 
 import torch
 import torch.distributed as dist
@@ -68,3 +72,41 @@ def gather_results(local_results, dst=0):
     if dist.get_rank() != dst:
         return None
     return [r for part in out for r in part]
+
+
+def launch_local_ranks(argv, n_ranks, timeout_s=None):
+    """Start `n_ranks` copies of `python argv...` on this node, one per GPU, with the torch.distributed rendezvous
+    environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) - what `torch.distributed.run --nnodes=1
+    --nproc-per-node N` would set. MUST be called before the calling process touches the GPU: the children are fresh
+    processes (never an exec of an initialised one). Rank 0 inherits stdout, the other ranks' stdout goes to stderr.
+    Returns the first non-zero exit code of any rank (0 if all succeeded); when one rank fails the others are stopped."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = None if timeout_s is None else time.time() + timeout_s
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in live:      # a failed rank would leave the others waiting in a collective forever
+                    other.terminate()
+        if deadline is not None and time.time() > deadline:
+            for other in live:
+                other.kill()
+            return rc or 124
+        if live:
+            time.sleep(0.05)
+    return rc

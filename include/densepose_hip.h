@@ -91,6 +91,34 @@ int dp_conv2d_kernel_class(const dp_conv_params* p);
  * steps of 32 to fit the launch into whole rounds of the chip) - profiling / roofline bookkeeping only */
 int dp_conv2d_tile_rows(const dp_conv_params* p);
 
+/* ---------------------------------------------------------------------------------------------
+ * K4  resnet.py:189-205  BottleneckBlock.forward, everything after conv1, in ONE launch:
+ *       t2  = relu(conv2(t1) + b2)                 3x3, Cmid -> Cmid         (resnet.py:195-197)
+ *       out = relu(conv3(t2) + b3 + residual)      1x1, Cmid -> Cout         (resnet.py:199-205)
+ *       next_t1 = relu(conv1'(out) + b1')          1x1, Cout -> Cmid_next: conv1 of the NEXT block
+ *                                                  (resnet.py:192-193), optional (next_t1 == NULL: skipped)
+ * Weights, tap table and biases are the packed operands dp_conv2d_nhwc takes for the same layers
+ * (FrozenBN folded, batch_norm.py:54-62); results are bit-identical to three dp_conv2d_nhwc calls.
+ * Fused shapes: dp_bottleneck_tail_supported() (16-bit storage, Cmid 64, Cout 256 = the res2 blocks);
+ * anything else returns DP_ERR_UNSUPPORTED and the caller runs the layers one by one.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* t1;        /* [N][H][W][Cmid] dtype: conv1 output of this block */
+  const void* residual;  /* [N][H][W][Cout] dtype: block input or its shortcut projection */
+  void* out;             /* [N][H][W][Cout] dtype */
+  void* next_t1;         /* optional [N][H][W][Cmid_next] dtype */
+  const void* w2; const void* w3; const void* w1n;   /* packed weights ([Cout_w][Kpad], see dp_conv_params) */
+  const int32_t* ktab2;  /* conv2's tap table */
+  const float* b2; const float* b3; const float* b1n;
+  int32_t N, H, W;
+  int32_t Cmid, Cout, Cmid_next;
+  int32_t Kpad2, Kpad3, Kpad1n;
+  int32_t ntaps2, hi_off2, wi_off2;
+  int32_t dtype;
+} dp_bottleneck_params;
+int dp_bottleneck_tail_supported(const dp_bottleneck_params* p);
+int dp_bottleneck_tail_nhwc(const dp_bottleneck_params* p, dp_stream_t stream);
+
 /* K3  resnet.py:353  F.max_pool2d(k=3, s=2, p=1), NHWC */
 int dp_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, dp_stream_t stream);
 

@@ -42,6 +42,16 @@ def test_argument_validation_without_gpu(built):
     p.N, p.H, p.W, p.Ho, p.Wo, p.Cin, p.Cout = 1, 4, 4, 4, 4, 7, 8
     rc = lib.dp_conv2d_nhwc(ctypes.byref(p), None)
     assert rc == -1 and b"null pointer" in lib.dp_last_error()
+    b = built.BottleneckParams()
+    b.N, b.H, b.W, b.Cmid, b.Cout, b.Kpad2, b.Kpad3, b.ntaps2, b.dtype = 1, 8, 8, 64, 256, 576, 64, 9, built.DP_F32
+    assert lib.dp_bottleneck_tail_supported(ctypes.byref(b)) == 0          # fp32 parity mode has no fused kernel
+    assert lib.dp_bottleneck_tail_nhwc(ctypes.byref(b), None) == -2 and b"16-bit" in lib.dp_last_error()
+    b.dtype = built.DP_BF16
+    assert lib.dp_bottleneck_tail_supported(ctypes.byref(b)) == 1
+    assert lib.dp_bottleneck_tail_nhwc(ctypes.byref(b), None) == -1 and b"null pointer" in lib.dp_last_error()
+    b.N = 64                                                                 # 64 x 200 x 336 pixels x 512 B > 2^31: caller must chunk
+    b.H, b.W = 200, 336
+    assert lib.dp_bottleneck_tail_supported(ctypes.byref(b)) == 0
     q = built.NmsParams()
     assert lib.dp_batched_nms(ctypes.byref(q), None) == -1
     assert lib.dp_nms_workspace_bytes(2, 1000) > 2 * 1000 * 16 * 8
@@ -52,6 +62,7 @@ def test_struct_layout_matches_c(built, tmp_path):
     """sizeof() of every parameter struct as seen by a C compiler == ctypes.sizeof of its mirror."""
     import subprocess
     names = {"dp_preprocess_params": built.PreprocessParams, "dp_conv_params": built.ConvParams,
+             "dp_bottleneck_params": built.BottleneckParams,
              "dp_rpn_level_params": built.RpnLevelParams, "dp_nms_params": built.NmsParams,
              "dp_roi_align_params": built.RoiAlignParams, "dp_box_decode_params": built.BoxDecodeParams,
              "dp_postprocess_params": built.PostprocessParams, "dp_iuv_params": built.IuvParams,

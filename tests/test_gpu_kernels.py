@@ -182,6 +182,88 @@ def test_conv2d_matches_torch(eng, dt, case):
         assert bool(((got16 - ref).abs() <= bound).all()), (case, float((got16 - ref).abs().max()))
 
 
+TAIL_CASES = [
+    # N, H, W, with next conv1
+    (1, 20, 24, True),
+    (2, 17, 19, True),      # ragged: rows and the pixel count are no multiple of the 16 / 32-pixel tiles
+    (3, 40, 37, False),
+    (1, 1, 1, True),        # a single pixel: every tap but the centre is padding
+    (2, 3, 70, True),
+    (1, 96, 160, True),     # more wave tiles than one round of the chip takes (persistent loop, in-place prefetch)
+]
+
+
+def _tail_layers(e, seed):
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda co, ci, k: torch.randn((co, ci, k, k), generator=g) * (1.0 / (ci * k * k)) ** 0.5  # noqa: E731
+    w2, w3, w1 = mk(64, 64, 3), mk(256, 64, 1), mk(64, 256, 1)
+    b2, b3, b1 = (torch.randn((c,), generator=g) * 0.5 for c in (64, 256, 64))
+    l2 = conv_from_oihw("conv2", w2.numpy(), b2.numpy(), 64, 1, 1, 1, e.dt, e.device)
+    l3 = conv_from_oihw("conv3", w3.numpy(), b3.numpy(), 64, 1, 0, 1, e.dt, e.device)
+    l1 = conv_from_oihw("conv1n", w1.numpy(), b1.numpy(), 256, 1, 0, 1, e.dt, e.device)
+    return (l2, l3, l1), (w2, b2, w3, b3, w1, b1)
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", TAIL_CASES)
+def test_bottleneck_tail_equals_layer_by_layer(eng, dt, case):
+    """dp_bottleneck_tail_nhwc (conv2 -> conv3 + residual -> next conv1 chained through registers, resnet.py:189-205) is
+    BIT-identical to the three dp_conv2d_nhwc launches it replaces, and both agree with torch in fp64."""
+    from densepose_torchscript_amd.engine import Act
+    e = eng[dt]
+    N, H, W, with_next = case
+    (l2, l3, l1), (w2, b2, w3, b3, w1, b1) = _tail_layers(e, N * 1000 + H * 10 + W)
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    t1 = F.relu(torch.randn((N, 64, H, W), generator=g))
+    res = torch.randn((N, 256, H, W), generator=g)
+    t1, res = _round(t1, dt), _round(res, dt)
+    ta = Act(_nhwc(t1, 64, e.tdt, e.device), N, H, W, 64)
+    ra = Act(_nhwc(res, 256, e.tdt, e.device), N, H, W, 256)
+    t2 = e.conv(l2, ta, relu=True)
+    x_ref = e.conv(l3, t2, relu=True, residual=ra)
+    n_ref = e.conv(l1, x_ref, relu=True)
+    fused = e.bottleneck_tail(l2, l3, l1 if with_next else None, ta, ra)
+    assert fused is not None, "the library must have a fused kernel for the res2 shape"
+    x_f, n_f = fused
+    torch.cuda.synchronize()
+    assert torch.equal(x_f.t, x_ref.t)
+    if with_next:
+        assert torch.equal(n_f.t, n_ref.t)
+    else:
+        assert n_f is None
+    # and against torch (fp64 math on the same rounded operands; intermediate tensors rounded where the kernels store them)
+    rw = lambda w: _round(w, dt).double()  # noqa: E731
+    y2 = _round(F.relu(F.conv2d(t1.double(), rw(w2), b2.double(), padding=1)).float(), dt).double()
+    y3 = F.relu(F.conv2d(y2, rw(w3), b3.double()) + res.double())
+    got = x_f.t.float().cpu().permute(0, 3, 1, 2).double()
+    ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    assert bool(((got - y3).abs() <= 2 * ulp * y3.abs() + 2e-2).all()), float((got - y3).abs().max())
+
+
+def test_bottleneck_tail_unsupported_shapes_fall_back(eng):
+    """fp32 parity mode and non-res2 widths have no fused kernel: the engine helper says so instead of launching."""
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    e = eng["fp32"]
+    (l2, l3, l1), _ = _tail_layers(e, 1)
+    ta = Act(torch.zeros((1, 8, 8, 64), device=e.device), 1, 8, 8, 64)
+    ra = Act(torch.zeros((1, 8, 8, 256), device=e.device), 1, 8, 8, 256)
+    assert e.bottleneck_tail(l2, l3, l1, ta, ra) is None
+    eb = eng["bf16"]
+    g = torch.Generator().manual_seed(2)
+    w2 = torch.randn((32, 32, 3, 3), generator=g)
+    w3 = torch.randn((128, 32, 1, 1), generator=g)
+    l2s = conv_from_oihw("c2", w2.numpy(), np.zeros(32, np.float32), 32, 1, 1, 1, eb.dt, eb.device)
+    l3s = conv_from_oihw("c3", w3.numpy(), np.zeros(128, np.float32), 32, 1, 0, 1, eb.dt, eb.device)
+    ta = Act(torch.zeros((1, 8, 8, 32), dtype=eb.tdt, device=eb.device), 1, 8, 8, 32)
+    ra = Act(torch.zeros((1, 8, 8, 128), dtype=eb.tdt, device=eb.device), 1, 8, 8, 128)
+    assert eb.bottleneck_tail(l2s, l3s, None, ta, ra) is None
+    p = __import__("densepose_torchscript_amd.lib", fromlist=["x"]).BottleneckParams()
+    p.N, p.H, p.W, p.Cmid, p.Cout, p.Kpad2, p.Kpad3, p.ntaps2, p.dtype = 1, 8, 8, 32, 128, 288, 64, 9, eb.dt
+    assert eb.lib.dp_bottleneck_tail_nhwc(C.byref(p), eb._stream()) == -2   # DP_ERR_UNSUPPORTED
+
+
 def test_conv_fpn_lateral_plus_nearest_upsample(eng):
     from densepose_torchscript_amd.engine import Act
     from densepose_torchscript_amd.pack import conv_from_oihw
