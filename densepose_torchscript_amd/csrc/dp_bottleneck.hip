@@ -24,6 +24,16 @@
 #include "dp_common.h"
 #include "dp_mma.h"
 
+#ifndef DP_EXP
+#define DP_EXP 0
+#endif
+#ifndef DP_TAIL_NW
+#define DP_TAIL_NW 8   // waves per workgroup (one workgroup per CU)
+#endif
+#ifndef DP_TAIL_TP
+#define DP_TAIL_TP 1   // 16-pixel MFMA tiles per wave tile
+#endif
+
 namespace {
 
 struct TailArgs {
@@ -50,10 +60,20 @@ constexpr int kTailW1 = 8 * 64 * 64;                   // conv1': 8 planes x 64 
 constexpr int kTailBias = (64 + 256 + 64) * 4;
 constexpr int kTailLds = kTailW2 + kTailW3 + kTailW1 + kTailBias;
 
-template <typename T, bool HAS_NEXT>
-__global__ __launch_bounds__(256, 1) void bottleneck_tail64_kernel(const TailArgs p) {
+// One K step of the chain = 4 weight fragments (64 couts x 32 K) against the pixel fragments of the wave tile. The steps
+// of a tile are numbered 0..33: 0..17 conv2 (K plane s = tap s >> 1, channel block s & 1), 18..25 conv3 (64-cout block b, plane s), 26..33 conv1' (plane q);
+// the weight fragments of step k+1 are read from LDS into the other register set while the MFMAs of step k run.
+template <int K>
+__device__ __forceinline__ const unsigned char* tail_wfrag_addr(const unsigned char* w2_s, const unsigned char* w3_s, const unsigned char* w1_s) {
+  if constexpr (K < 18) return w2_s + K * 4096;
+  else if constexpr (K < 26) return w3_s + ((K - 18) & 1) * 16384 + ((K - 18) >> 1) * 4096;
+  else return w1_s + (K - 26) * 4096;
+}
+
+template <typename T, bool HAS_NEXT, int NW, int TP>
+__global__ __launch_bounds__(NW * 64, NW / 4) void bottleneck_tail64_kernel(const TailArgs p) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
-  constexpr int TP = 2;                  // 32 pixels per wave tile
+  constexpr int NSTEP = HAS_NEXT ? 34 : 26;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const w2_s = smem;
   unsigned char* const w3_s = smem + kTailW2;
@@ -72,27 +92,27 @@ __global__ __launch_bounds__(256, 1) void bottleneck_tail64_kernel(const TailArg
     const int srow = lane >> 2;
     const int scc = (lane & 3) ^ swz(srow);
     const T* __restrict__ w2 = reinterpret_cast<const T*>(p.w2) + (long long)srow * p.kpad2 + scc * 8;
-    for (int piece = wave; piece < 18 * 4; piece += 4) {
+    for (int piece = wave; piece < 18 * 4; piece += NW) {
       const int pl = piece >> 2, rg = piece & 3;
       __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w2 + (long long)(rg * 16) * p.kpad2 + pl * 32),
                                        DP_LDS_PTR(w2_s + pl * 4096 + rg * 1024), 16, 0, 0);
     }
     const T* __restrict__ w3 = reinterpret_cast<const T*>(p.w3) + (long long)srow * p.kpad3 + scc * 8;
-    for (int piece = wave; piece < 2 * 16; piece += 4) {
+    for (int piece = wave; piece < 2 * 16; piece += NW) {
       const int pl = piece >> 4, rg = piece & 15;
       __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w3 + (long long)(rg * 16) * p.kpad3 + pl * 32),
                                        DP_LDS_PTR(w3_s + pl * 16384 + rg * 1024), 16, 0, 0);
     }
     if (HAS_NEXT) {
       const T* __restrict__ w1 = reinterpret_cast<const T*>(p.w1n) + (long long)srow * p.kpad1n + scc * 8;
-      for (int piece = wave; piece < 8 * 4; piece += 4) {
+      for (int piece = wave; piece < 8 * 4; piece += NW) {
         const int pl = piece >> 2, rg = piece & 3;
         __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w1 + (long long)(rg * 16) * p.kpad1n + pl * 32),
                                          DP_LDS_PTR(w1_s + pl * 4096 + rg * 1024), 16, 0, 0);
       }
     }
     if (tid < 64) b2_s[tid] = p.b2[tid];
-    b3_s[tid] = p.b3[tid];
+    if (tid < 256) b3_s[tid] = p.b3[tid];
     if (HAS_NEXT && tid < 64) b1_s[tid] = p.b1n[tid];
   }
   __syncthreads();  // (vmcnt(0) + barrier)
@@ -100,197 +120,203 @@ __global__ __launch_bounds__(256, 1) void bottleneck_tail64_kernel(const TailArg
   const int fr = lane & 15;
   const int fq = lane >> 4;
   const int rd = fr * 64 + ((fq ^ swz(fr)) << 4);   // fragment read offset inside a 16-row group of a plane
-  const int n_wt = (p.M + 31) >> 5;
-  const int wt_step = gridDim.x * 4;
-  int wt = blockIdx.x * 4 + wave;
+  const int n_wt = (p.M + 16 * TP - 1) / (16 * TP);
+  const int wt_step = gridDim.x * NW;
+  int wt = blockIdx.x * NW + wave;
   if (wt >= n_wt) return;
 
-  // the 9 taps of conv2 (wave-uniform): pixel displacement and its byte offset in the 128-byte-per-pixel t1 tensor
+  // the 3 x 3 taps of conv2 (wave-uniform; pack.py enumerates them row-major: tap t = row t / 3, column t % 3): pixel
+  // displacement and byte offset in the 128-byte-per-pixel t1 tensor. K is packed TAP-major (plane s = tap s >> 1, channel
+  // block s & 1): the two 64-byte halves of a t1 pixel (one 128-byte line) are fetched by consecutive loads.
   const __attribute__((address_space(4))) i32x4* ktab_c = (const __attribute__((address_space(4))) i32x4*)p.ktab2;
-  int tdy[9], tdx[9], toff[9];
+  int tdy[3], tdx[3], toff[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const i32x4 e = ktab_c[t * 4];   // planes 0..8 of the channel-block-major packing enumerate the taps
-    tdy[t] = e[0] + p.hi_off;
-    tdx[t] = e[1] + p.wi_off;
-    toff[t] = (tdy[t] * p.W + tdx[t]) * 128;
+  for (int i = 0; i < 3; ++i) {
+    tdy[i] = ktab_c[i * 3 * 8][0] + p.hi_off;   // ktab holds one entry per 16-byte K chunk: 8 per tap (64 channels)
+    tdx[i] = ktab_c[i * 8][1] + p.wi_off;
   }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) toff[t] = (tdy[t / 3] * p.W + tdx[t % 3]) * 128;
+  // a wave's consecutive tiles are wt_step tiles apart: (row, column) of a pixel advance by a constant (dh, dw) + carry
   const int HW = p.H * p.W;
+  const int step_px = wt_step * 16 * TP;
+  const int dstep = step_px % HW, dh = dstep / p.W, dw = dstep - dh * p.W;
 
   const __amdgpu_buffer_rsrc_t rs_t1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.t1), 0, p.t1_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_t1n = __builtin_amdgcn_make_buffer_rsrc(HAS_NEXT ? p.t1n : p.out, 0, HAS_NEXT ? p.t1n_bytes : 0u, 0x00020000);
 
-  // per-lane view of a wave tile: pixel m of each of the two 16-pixel MFMA tiles, the bit mask of the taps that fall inside
-  // the image for that pixel, and its byte offset (chunk fq) in t1. Pixels >= M get an empty mask and out-of-range offsets.
-  auto tile_geom = [&](int tile, int (&m)[TP], unsigned (&okm)[TP]) __attribute__((always_inline)) {
+  // per-lane view of a wave tile: pixel m (row ho, column wo) of each 16-pixel MFMA tile and, per tap, the byte offset of
+  // this lane's 16-byte piece (chunk fq of channel block 0) in t1 - or an out-of-range offset when the tap falls outside
+  // the image or the pixel is >= M (the load then returns zeros without touching memory).
+  struct Geom { int m, ho, wo; };
+  auto tap_offsets = [&](const Geom& g, int (&voff)[9]) __attribute__((always_inline)) {
+    const bool live = g.m < p.M;
+    bool rok[3], cok[3];
 #pragma unroll
-    for (int j = 0; j < TP; ++j) {
-      m[j] = tile * 32 + j * 16 + fr;
-      okm[j] = 0u;
-      if (m[j] < p.M) {
-        const int n = m[j] / HW;
-        const int rem = m[j] - n * HW;
-        const int ho = rem / p.W;
-        const int wo = rem - ho * p.W;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-          if ((unsigned)(ho + tdy[t]) < (unsigned)p.H && (unsigned)(wo + tdx[t]) < (unsigned)p.W) okm[j] |= 1u << t;
-      }
+    for (int i = 0; i < 3; ++i) {
+      rok[i] = live && (unsigned)(g.ho + tdy[i]) < (unsigned)p.H;
+      cok[i] = (unsigned)(g.wo + tdx[i]) < (unsigned)p.W;
     }
+    const int base = g.m * 128 + fq * 16;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) voff[t] = (rok[t / 3] && cok[t % 3]) ? base + toff[t] : (int)0x80000000;
   };
-  auto tap_load = [&](int s, int mj, unsigned okm) __attribute__((always_inline)) -> u32x4 {
-    const int t = s % 9, cb = s / 9;   // K plane s = channel block cb, tap t
-    const int off = ((okm >> t) & 1u) ? (mj * 128 + fq * 16 + toff[t] + cb * 64) : (int)0x80000000;
-    return __builtin_amdgcn_raw_buffer_load_b128(rs_t1, off, 0, 0);
+  auto advance = [&](Geom& g) __attribute__((always_inline)) {
+    g.m += step_px;
+    g.wo += dw;
+    const int c = g.wo >= p.W ? 1 : 0;
+    g.wo -= c ? p.W : 0;
+    g.ho += dh + c;
+    g.ho -= g.ho >= p.H ? p.H : 0;
   };
 
   u32x4 a[18][TP];      // conv2 operand fragments of the CURRENT tile (refilled in place with the next one)
   u32x4 r[TP][8];       // residual runs of the current tile
-  int m_cur[TP], m_nxt[TP];
-  unsigned ok_cur[TP], ok_nxt[TP];
-  tile_geom(wt, m_cur, ok_cur);
+  Geom g[TP];
+  int m_cur[TP];
+  int voff[TP][9];
 #pragma unroll
   for (int j = 0; j < TP; ++j) {
+    g[j].m = (wt * TP + j) * 16 + fr;
+    const int rem = g[j].m % HW;
+    g[j].ho = rem / p.W;
+    g[j].wo = rem - g[j].ho * p.W;
+    tap_offsets(g[j], voff[j]);
 #pragma unroll
-    for (int s = 0; s < 18; ++s) a[s][j] = tap_load(s, m_cur[j], ok_cur[j]);
+    for (int s = 0; s < 18; ++s) a[s][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_t1, voff[j][s >> 1] + (s & 1) * 64, 0, 0);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) r[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, m_cur[j] * 512 + q * 64 + fq * 16, 0, 0);
+    for (int q = 0; q < 8; ++q) r[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, g[j].m * 512 + q * 64 + fq * 16, 0, 0);
   }
 
   for (; wt < n_wt; wt += wt_step) {
-    tile_geom(wt + wt_step, m_nxt, ok_nxt);   // past the end: every pixel >= M
-
-    // ---- conv2: 18 K planes, A = W2 fragments from LDS, B = tap fragments in registers
-    f32x4 acc2[4][TP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < TP; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 18; ++s) {
-      u32x4 wf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const u32x4*>(w2_s + s * 4096 + i * 1024 + rd);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < TP; ++j) Mma<T>::run(wf[i], a[s][j], acc2[i][j]);
-#pragma unroll
-      for (int j = 0; j < TP; ++j) a[s][j] = tap_load(s, m_nxt[j], ok_nxt[j]);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < TP; ++j) {
+      m_cur[j] = g[j].m;
+      advance(g[j]);                  // past the end: every pixel >= M
+      tap_offsets(g[j], voff[j]);
     }
 
-    // ---- t2 = relu(acc2 + b2), rounded to the storage type: run h of pixel tile j is conv3's B fragment of K plane h
-    u32x4 tf[2][TP];
+    u32x4 wfA[4], wfB[4];
+    u32x4 tf[2][TP];      // t2 (conv3's B fragments)
+    u32x4 xf[8][TP];      // block output (conv1''s B fragments)
+    f32x4 acc[4][TP];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(b2_s + h * 32 + fq * 8);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(b2_s + h * 32 + fq * 8 + 4);
+    for (int i = 0; i < 4; ++i) wfA[i] = *reinterpret_cast<const u32x4*>(w2_s + i * 1024 + rd);
+
+    static_for<0, NSTEP>([&](auto kk) {
+      constexpr int K = decltype(kk)::value;
+      u32x4 (&wf)[4] = (K & 1) ? wfB : wfA;
+      u32x4 (&wn)[4] = (K & 1) ? wfA : wfB;
+      // weight fragments of the next step fly while this step's MFMAs run
+      if constexpr (K + 1 < NSTEP) {
+        const unsigned char* nx = tail_wfrag_addr<K + 1>(w2_s, w3_s, w1_s) + rd;
 #pragma unroll
-      for (int j = 0; j < TP; ++j) {
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          v[k] = fmaxf(acc2[2 * h][j][k] + b0[k], 0.f);
-          v[4 + k] = fmaxf(acc2[2 * h + 1][j][k] + b1[k], 0.f);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) tf[h][j][k] = Elem<T>::pack2(v[2 * k], v[2 * k + 1]);
+        for (int i = 0; i < 4; ++i) wn[i] = *reinterpret_cast<const u32x4*>(nx + i * 1024);
       }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- conv3 (four 64-cout blocks) + bias + residual + ReLU -> out; the packed runs stay in registers for conv1'
-    u32x4 xf[8][TP];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      f32x4 acc3[4][TP];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < TP; ++j) acc3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        u32x4 wf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const u32x4*>(w3_s + s * 16384 + (b * 64 + i * 16) * 64 + rd);
+      if constexpr (K == 0 || (K >= 18 && ((K - 18) & 1) == 0 && K < 26) || K == 26) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < TP; ++j) Mma<T>::run(wf[i], tf[s][j], acc3[i][j]);
+          for (int j = 0; j < TP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int q = 2 * b + h;
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(b3_s + q * 32 + fq * 8);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(b3_s + q * 32 + fq * 8 + 4);
-#pragma unroll
-        for (int j = 0; j < TP; ++j) {
-          float v[8];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v[k] = acc3[2 * h][j][k] + b0[k];
-            v[4 + k] = acc3[2 * h + 1][j][k] + b1[k];
-          }
-          const u32x4 rv = r[j][q];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v[2 * k] += Elem<T>::unpack(rv[k] & 0xffffu);
-            v[2 * k + 1] += Elem<T>::unpack(rv[k] >> 16);
-          }
-          r[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, m_nxt[j] * 512 + q * 64 + fq * 16, 0, 0);
-          u32x4 pk;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) pk[k] = Elem<T>::pack2(fmaxf(v[2 * k], 0.f), fmaxf(v[2 * k + 1], 0.f));
-          __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, m_cur[j] * 512 + q * 64 + fq * 16, 0, 0);
-          xf[q][j] = pk;
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---- conv1' of the next block: K = the 256 channels just produced (8 planes = the 8 runs above)
-    if (HAS_NEXT) {
-      f32x4 acc1[4][TP];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < TP; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        u32x4 wf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const u32x4*>(w1_s + q * 4096 + i * 1024 + rd);
+      if constexpr (K < 18) {
+        // ---- conv2, K plane K: B = tap fragments in registers
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < TP; ++j) Mma<T>::run(wf[i], xf[q][j], acc1[i][j]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+          for (int j = 0; j < TP; ++j) Mma<T>::run(wf[i], a[K][j], acc[i][j]);
+        if (!(DP_EXP & 1)) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(b1_s + h * 32 + fq * 8);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(b1_s + h * 32 + fq * 8 + 4);
+          for (int j = 0; j < TP; ++j) a[K][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_t1, voff[j][K >> 1] + (K & 1) * 64, 0, 0);
+        }
+        if constexpr (K == 17) {
+          // t2 = relu(acc + b2), rounded to the storage type: run h of pixel tile j is conv3's B fragment of K plane h
 #pragma unroll
-        for (int j = 0; j < TP; ++j) {
-          float v[8];
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(b2_s + h * 32 + fq * 8);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(b2_s + h * 32 + fq * 8 + 4);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v[k] = fmaxf(acc1[2 * h][j][k] + b0[k], 0.f);
-            v[4 + k] = fmaxf(acc1[2 * h + 1][j][k] + b1[k], 0.f);
+            for (int j = 0; j < TP; ++j) {
+              float v[8];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                v[k] = fmaxf(acc[2 * h][j][k] + b0[k], 0.f);
+                v[4 + k] = fmaxf(acc[2 * h + 1][j][k] + b1[k], 0.f);
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) tf[h][j][k] = Elem<T>::pack2(v[2 * k], v[2 * k + 1]);
+            }
           }
-          u32x4 pk;
+        }
+      } else if constexpr (K < 26) {
+        // ---- conv3, 64-cout block b, K plane s (+ bias + residual + ReLU -> out after the second plane)
+        constexpr int b = (K - 18) >> 1, sp = (K - 18) & 1;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) pk[k] = Elem<T>::pack2(v[2 * k], v[2 * k + 1]);
-          __builtin_amdgcn_raw_buffer_store_b128(pk, rs_t1n, m_cur[j] * 128 + h * 64 + fq * 16, 0, 0);
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < TP; ++j) Mma<T>::run(wf[i], tf[sp][j], acc[i][j]);
+        if constexpr (sp == 1) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            constexpr int qb = 2 * b;
+            const int q = qb + h;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(b3_s + q * 32 + fq * 8);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(b3_s + q * 32 + fq * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+              float v[8];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                v[k] = acc[2 * h][j][k] + b0[k];
+                v[4 + k] = acc[2 * h + 1][j][k] + b1[k];
+              }
+              const u32x4 rv = r[j][q];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                v[2 * k] += Elem<T>::unpack(rv[k] & 0xffffu);
+                v[2 * k + 1] += Elem<T>::unpack(rv[k] >> 16);
+              }
+              if (!(DP_EXP & 2)) r[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, g[j].m * 512 + q * 64 + fq * 16, 0, 0);
+              u32x4 pk;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) pk[k] = Elem<T>::pack2(fmaxf(v[2 * k], 0.f), fmaxf(v[2 * k + 1], 0.f));
+              if (!(DP_EXP & 4) || pk[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, m_cur[j] * 512 + q * 64 + fq * 16, 0, 0);
+              xf[q][j] = pk;
+            }
+          }
+        }
+      } else {
+        // ---- conv1' of the next block: K = the 256 channels just produced (plane q = run q above)
+        constexpr int q = K - 26;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < TP; ++j) Mma<T>::run(wf[i], xf[q][j], acc[i][j]);
+        if constexpr (q == 7) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(b1_s + h * 32 + fq * 8);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(b1_s + h * 32 + fq * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+              float v[8];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                v[k] = fmaxf(acc[2 * h][j][k] + b0[k], 0.f);
+                v[4 + k] = fmaxf(acc[2 * h + 1][j][k] + b1[k], 0.f);
+              }
+              u32x4 pk;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) pk[k] = Elem<T>::pack2(v[2 * k], v[2 * k + 1]);
+              if (!(DP_EXP & 4) || pk[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(pk, rs_t1n, m_cur[j] * 128 + h * 64 + fq * 16, 0, 0);
+            }
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int j = 0; j < TP; ++j) { m_cur[j] = m_nxt[j]; ok_cur[j] = ok_nxt[j]; }
+    });
   }
 }
 
@@ -304,18 +330,19 @@ static int tail_num_cus() {
 
 template <typename T, bool HAS_NEXT>
 int launch_tail(const TailArgs& a, hipStream_t stream) {
+  constexpr int NW = DP_TAIL_NW, TP = DP_TAIL_TP;
   static bool attr_set = false;
   static int cus = 0;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_tail64_kernel<T, HAS_NEXT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_tail64_kernel<T, HAS_NEXT, NW, TP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds);
     cus = tail_num_cus();
     attr_set = true;
   }
-  const int n_wt = (a.M + 31) / 32;
+  const int n_wt = (a.M + 16 * TP - 1) / (16 * TP);
   int gx = cus;
-  if (gx > (n_wt + 3) / 4) gx = (n_wt + 3) / 4;
-  hipLaunchKernelGGL((bottleneck_tail64_kernel<T, HAS_NEXT>), dim3(gx), dim3(256), kTailLds, stream, a);
+  if (gx > (n_wt + NW - 1) / NW) gx = (n_wt + NW - 1) / NW;
+  hipLaunchKernelGGL((bottleneck_tail64_kernel<T, HAS_NEXT, NW, TP>), dim3(gx), dim3(NW * 64), kTailLds, stream, a);
   return dp_check_launch("bottleneck_tail64_kernel");
 }
 
@@ -327,6 +354,7 @@ static const char* tail_unsupported(const dp_bottleneck_params* p) {
   if (p->dtype != DP_BF16 && p->dtype != DP_F16) return "16-bit storage only";
   if (p->Cmid != 64 || p->Cout != 256) return "only the 64 -> 64 -> 256 (res2) shape is fused";
   if (p->ntaps2 != 9 || p->Kpad2 != 576 || p->Kpad3 != 64) return "conv2 must be 3x3 over 64 channels (Kpad 576), conv3 1x1 (Kpad 64)";
+  if (p->k_order2 != 1) return "conv2 must be packed tap-major (K = tap * 64 + channel)";
   if (p->next_t1 && (p->Cmid_next != 64 || p->Kpad1n != 256)) return "next conv1 must be 256 -> 64 (Kpad 256)";
   const long long M = (long long)p->N * p->H * p->W;
   // 32-bit buffer offsets; pixels up to one grid stride of tiles past the end are addressed before the range check drops them

@@ -303,14 +303,6 @@ __device__ __forceinline__ void wait_planes(int planes, int pw) {
   else { if (pw == 4) wait_vmcnt<8>(); else wait_vmcnt<6>(); }
 }
 
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
 template <typename T, int WC, int TP>
 __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArgs p) {
   constexpr int ES = sizeof(T);

@@ -1,6 +1,7 @@
 // MFMA operand conventions shared by the convolution kernels (dp_conv.hip, dp_bottleneck.hip).
 #pragma once
 #include "dp_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -35,6 +36,14 @@ struct Mma<float> {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], c, 0, 0, 0);
   }
 };
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 #define DP_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define DP_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))

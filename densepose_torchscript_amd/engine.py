@@ -142,6 +142,7 @@ class Engine:
         p.Cmid, p.Cout, p.Cmid_next = l2.cout, l3.cout, (l1n.cout if l1n is not None else 0)
         p.Kpad2, p.Kpad3, p.Kpad1n = l2.kpad, l3.kpad, (l1n.kpad if l1n is not None else 0)
         p.ntaps2, p.hi_off2, p.wi_off2, p.dtype = l2.ntaps, l2.hi_off, l2.wi_off, self.dt
+        p.k_order2 = 0 if l2.plane_major else 1
         if (l2.stride != 1 or l3.stride != 1 or l3.ntaps != 1 or t1.C != l2.cin or l2.cout != l3.cin or residual.C != l3.cout
                 or (l1n is not None and (l1n.stride != 1 or l1n.ntaps != 1 or l1n.cin != l3.cout))):
             return None

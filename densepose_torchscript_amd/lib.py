@@ -44,7 +44,7 @@ class BottleneckParams(C.Structure):
                 ("N", c_i32), ("H", c_i32), ("W", c_i32),
                 ("Cmid", c_i32), ("Cout", c_i32), ("Cmid_next", c_i32),
                 ("Kpad2", c_i32), ("Kpad3", c_i32), ("Kpad1n", c_i32),
-                ("ntaps2", c_i32), ("hi_off2", c_i32), ("wi_off2", c_i32),
+                ("ntaps2", c_i32), ("hi_off2", c_i32), ("wi_off2", c_i32), ("k_order2", c_i32),
                 ("dtype", c_i32)]
 
 

@@ -38,7 +38,7 @@ COUT_ROW_PERM = _cout_row_perm()
 class PackedConv:
     """One dp_conv2d_nhwc layer resident on the device."""
 
-    def __init__(self, name, wmat, taps, bias, cin_alloc, cout, stride, hi_off, wi_off, dtype, device):
+    def __init__(self, name, wmat, taps, bias, cin_alloc, cout, stride, hi_off, wi_off, dtype, device, plane_major=None):
         # wmat: float32 [Cout, ntaps, Cin] ; taps: list of (dy, dx)
         self.name = name
         self.dtype = dtype
@@ -58,7 +58,14 @@ class PackedConv:
         # taps inner: consecutive K planes then read the same pixels shifted by one tap, so the 3 dx taps (and, through
         # the neighbouring tiles that run at the same time on the same XCD, the 3 dy taps) of an activation hit in L2
         # instead of being re-fetched from beyond it 9 times (tap-major order sweeps the whole input once per tap).
-        self.plane_major = nt > 1 and cin_alloc % pe == 0
+        # plane_major=False (opt-in, PackedModel uses it for the res2 conv2 layers) keeps K TAP major - K = tap * Cin +
+        # channel - which is what the fused bottleneck tail (dp_bottleneck_tail_nhwc) consumes: the two 64-byte halves of a
+        # pixel's 128-byte line are then read by consecutive loads. Only for layers that run on the table-driven generic
+        # kernel (Cout <= 64): the LDS-ring kernels enumerate the taps as planes 0..ntaps-1 of the channel-block-major order.
+        if plane_major is None:
+            plane_major = True
+        assert plane_major or co <= 64, "tap-major packing is only legal for layers on the generic kernel (Cout <= 64)"
+        self.plane_major = bool(plane_major) and nt > 1 and cin_alloc % pe == 0
         if self.plane_major:
             ncb = cin_alloc // pe
             full = full.reshape(self.cout_w, nt, ncb, pe).transpose(0, 2, 1, 3)  # [co, cblock, tap, pe]
@@ -109,7 +116,7 @@ def _fold_bn(w, st, norm_name):
     return w * scale[:, None, None, None], shift
 
 
-def conv_from_oihw(name, w, bias, cin_alloc, stride, pad, dil, dtype, device, in_hw=None):
+def conv_from_oihw(name, w, bias, cin_alloc, stride, pad, dil, dtype, device, in_hw=None, plane_major=None):
     co, ci, R, S = w.shape
     taps, cols = [], []
     for r in range(R):
@@ -124,7 +131,7 @@ def conv_from_oihw(name, w, bias, cin_alloc, stride, pad, dil, dtype, device, in
             taps.append((dy, dx))
             cols.append(w[:, :, r, s])
     wmat = np.stack(cols, axis=1).astype(np.float32)  # [co, ntaps, ci]
-    return PackedConv(name, wmat, taps, bias, cin_alloc, co, stride, -pad, -pad, dtype, device)
+    return PackedConv(name, wmat, taps, bias, cin_alloc, co, stride, -pad, -pad, dtype, device, plane_major=plane_major)
 
 
 def linear_as_conv(name, w, bias, cin_alloc, dtype, device):
@@ -161,9 +168,9 @@ class PackedModel:
         st = state
         bu = "backbone.bottom_up."
 
-        def bnconv(name, cin_alloc, stride, pad):
+        def bnconv(name, cin_alloc, stride, pad, plane_major=None):
             w, shift = _fold_bn(st[name + ".weight"].astype(np.float32), st, name + ".norm")
-            return conv_from_oihw(name, w, shift, cin_alloc, stride, pad, 1, dtype, device)
+            return conv_from_oihw(name, w, shift, cin_alloc, stride, pad, 1, dtype, device, plane_major=plane_major)
 
         def bconv(name, cin_alloc, stride=1, pad=0, dil=1, in_hw=None, bias=True):
             return conv_from_oihw(name, st[name + ".weight"].astype(np.float32),
@@ -176,7 +183,8 @@ class PackedModel:
             if sc:
                 L[p + "shortcut"] = bnconv(p + "shortcut", A8(cin), stride, 0)
             L[p + "conv1"] = bnconv(p + "conv1", A8(cin), stride, 0)
-            L[p + "conv2"] = bnconv(p + "conv2", A8(cmid), 1, 1)
+            # 64 -> 64 3x3 in 16-bit storage (the res2 blocks): tap-major K for the fused bottleneck tail
+            L[p + "conv2"] = bnconv(p + "conv2", A8(cmid), 1, 1, plane_major=False if (cmid == 64 and dtype != DP_F32) else None)
             L[p + "conv3"] = bnconv(p + "conv3", A8(cmid), 1, 0)
         c = cfg.res2_out
         F = A8(cfg.fpn_out)

@@ -114,6 +114,8 @@ typedef struct {
   int32_t Cmid, Cout, Cmid_next;
   int32_t Kpad2, Kpad3, Kpad1n;
   int32_t ntaps2, hi_off2, wi_off2;
+  int32_t k_order2;      /* K order of conv2's packed weights: 0 = channel-block major (64-byte planes outer, taps inner),
+                            1 = tap major (K = tap * Cmid + channel); the fused kernel takes 1 */
   int32_t dtype;
 } dp_bottleneck_params;
 int dp_bottleneck_tail_supported(const dp_bottleneck_params* p);

@@ -43,7 +43,7 @@ def test_argument_validation_without_gpu(built):
     rc = lib.dp_conv2d_nhwc(ctypes.byref(p), None)
     assert rc == -1 and b"null pointer" in lib.dp_last_error()
     b = built.BottleneckParams()
-    b.N, b.H, b.W, b.Cmid, b.Cout, b.Kpad2, b.Kpad3, b.ntaps2, b.dtype = 1, 8, 8, 64, 256, 576, 64, 9, built.DP_F32
+    b.N, b.H, b.W, b.Cmid, b.Cout, b.Kpad2, b.Kpad3, b.ntaps2, b.k_order2, b.dtype = 1, 8, 8, 64, 256, 576, 64, 9, 1, built.DP_F32
     assert lib.dp_bottleneck_tail_supported(ctypes.byref(b)) == 0          # fp32 parity mode has no fused kernel
     assert lib.dp_bottleneck_tail_nhwc(ctypes.byref(b), None) == -2 and b"16-bit" in lib.dp_last_error()
     b.dtype = built.DP_BF16

@@ -199,7 +199,7 @@ def _tail_layers(e, seed):
     mk = lambda co, ci, k: torch.randn((co, ci, k, k), generator=g) * (1.0 / (ci * k * k)) ** 0.5  # noqa: E731
     w2, w3, w1 = mk(64, 64, 3), mk(256, 64, 1), mk(64, 256, 1)
     b2, b3, b1 = (torch.randn((c,), generator=g) * 0.5 for c in (64, 256, 64))
-    l2 = conv_from_oihw("conv2", w2.numpy(), b2.numpy(), 64, 1, 1, 1, e.dt, e.device)
+    l2 = conv_from_oihw("conv2", w2.numpy(), b2.numpy(), 64, 1, 1, 1, e.dt, e.device, plane_major=False)   # tap-major K, as PackedModel packs it
     l3 = conv_from_oihw("conv3", w3.numpy(), b3.numpy(), 64, 1, 0, 1, e.dt, e.device)
     l1 = conv_from_oihw("conv1n", w1.numpy(), b1.numpy(), 256, 1, 0, 1, e.dt, e.device)
     return (l2, l3, l1), (w2, b2, w3, b3, w1, b1)
