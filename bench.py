@@ -2,7 +2,11 @@
 """Headline benchmark (BASELINE.json): images/sec of the DensePose hot path on R_50_FPN_s1x, 800x1333 frames,
 batch 8 per GPU, bf16 operands / fp32 accumulate, detections pinned to R = 8 per image.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU. Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS a rank; run
+bare (`python bench.py --gpus 8`) it starts the N ranks itself as child processes - before anything here touches the
+GPU - and exits with the first failing rank's code.
 
 A "step" = one pass of the whole path (device resize -> backbone -> RPN -> box head -> DensePose head -> IUV maps)
 over one batch of synthetic frames that are already resident in HBM. Prints ONE JSON line on rank 0.
@@ -32,7 +36,8 @@ def make_frames(n, start, hw, device):
 
 def cpu_baseline(cfg, state, hw, budget_s):
     """The oracle (a CPU port of the reference path, oracle/ref_cpu.py) timed on this box's host cores on a bounded
-    sample of the same workload (same weights, same frames, same R)."""
+    sample of the same workload (same weights, same frames, same R): 3 warm-up frames, then 10 timed ones,
+    fewer only if the box is so slow that 10 would not fit the budget."""
     from oracle.ref_cpu import OracleModel
     # torch's CPU convolutions stop scaling (and then collapse) beyond ~32 threads on this class of host
     # (measured on the 2x64-core EPYC GPU box: 3x3 conv 256->256 @200x336: 61 ms at 32 threads, 149 ms at 128, 595 ms at 256)
@@ -40,19 +45,100 @@ def cpu_baseline(cfg, state, hw, budget_s):
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     model = OracleModel(cfg, state)
-    frames = [torch.from_numpy(np.random.default_rng(1234 + i).integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)) for i in range(4)]
-    t0 = time.time()
-    model(frames[0])  # warm-up (also bounds the sample: if one frame is already slow, time fewer)
-    warm = time.time() - t0
-    n_timed = max(1, min(3, int(budget_s / max(warm, 1e-3))))
+    frames = [torch.from_numpy(np.random.default_rng(1234 + i).integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)) for i in range(8)]
+    warm = []
+    for i in range(3):
+        t0 = time.time()
+        model(frames[i])
+        warm.append(time.time() - t0)
+    n_timed = max(3, min(10, int(budget_s / max(min(warm), 1e-3))))
     times = []
     for i in range(n_timed):
         t0 = time.time()
-        model(frames[1 + i % 3])
+        model(frames[i % 8])
         times.append(time.time() - t0)
     return {"value": round(len(times) / sum(times), 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d frame(s) 800x1333 R_50_FPN_s1x fp32 after 1 warm-up, oracle/ref_cpu.py (torch %s CPU + C roi_align/nms), p50 %.0f ms/img"
-                      % (len(times), torch.__version__, 1e3 * float(np.median(times)))}
+            "sample": "%d frame(s) %dx%d %s fp32 after 3 warm-up frames, oracle/ref_cpu.py (torch %s CPU + C roi_align/nms), p50 %.0f ms/img"
+                      % (len(times), hw[0], hw[1], cfg.name if hasattr(cfg, "name") else "R_50_FPN_s1x", torch.__version__, 1e3 * float(np.median(times)))}
+
+
+def accuracy_vs_golden(pred, dtype):
+    """The throughput dtype against the reference's fp32 golden of the SAME workload (tests/golden/full_r50_s1x_800x1333.npz:
+    frame 0 of this benchmark, same weights, R = 8; recorded from the imported reference by oracle/make_goldens.py):
+    how many reference detections are found (box within 1 px, score within 0.02) and the largest IUV deviation on them."""
+    path = os.path.join(ROOT, "tests", "golden", "full_r50_s1x_800x1333.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    meta = json.loads(bytes(z["meta"]).decode())
+    img = np.random.default_rng(meta["image_seed"]).integers(0, 256, tuple(meta["image_hw"]) + (3,), dtype=np.uint8)
+    out = pred(torch.from_numpy(img).to(pred.device))
+    torch.cuda.synchronize()
+    s = meta["iuv_stride"]
+    boxes, scores = out["pred_boxes"].float().cpu().numpy(), out["scores"].float().cpu().numpy()
+    rb, rs = z["out/pred_boxes"], z["out/scores"]
+    matched, iuv_err, box_err, score_err = 0, 0.0, 0.0, 0.0
+    used = np.zeros(len(boxes), dtype=bool)
+    for i in range(len(rb)):
+        if not len(boxes):
+            break
+        d = np.abs(boxes - rb[i]).max(axis=1)
+        d[used] = np.inf
+        j = int(d.argmin())
+        if d[j] <= 1.0 and abs(float(scores[j]) - float(rs[i])) <= 0.02:
+            used[j] = True
+            matched += 1
+            box_err, score_err = max(box_err, float(d[j])), max(score_err, abs(float(scores[j]) - float(rs[i])))
+            for k in ("pred_densepose_coarse_segm", "pred_densepose_fine_segm", "pred_densepose_u", "pred_densepose_v"):
+                iuv_err = max(iuv_err, float(np.abs(out[k][j].float().cpu().numpy()[:, ::s, ::s] - z["out/" + k][i]).max()))
+    return {"reference": "tests/golden/full_r50_s1x_800x1333.npz (fp32, recorded from the imported reference)", "dtype": dtype,
+            "ref_detections": int(len(rb)), "detections": int(len(boxes)), "box_match_rate": round(matched / max(len(rb), 1), 3),
+            "max_abs_box_err_px": round(box_err, 4), "max_abs_score_err": round(score_err, 5),
+            "max_abs_iuv_err_on_matched": round(iuv_err, 4), "iuv_samples": "every %dth pixel of the 112x112 maps" % s}
+
+
+def r_sensitivity(args, state, frames, device):
+    """images/s of the same workload with the detection count pinned to R = 0 and to R = 100 per image (the
+    DensePose head costs 28.7 GFLOP per detection, so the result is linear in R; the headline runs at R = 8)."""
+    from densepose_torchscript_amd import get_config
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    out = {}
+    for label, opts in (("R0", ["TEST.DETECTIONS_PER_IMAGE", 8, "MODEL.ROI_HEADS.SCORE_THRESH_TEST", 2.0]),
+                        ("R100", ["TEST.DETECTIONS_PER_IMAGE", 100, "MODEL.ROI_HEADS.SCORE_THRESH_TEST", 0.0])):
+        cfg = get_config(args.config, opts)
+        p = DensePosePredictor(cfg, state, dtype=args.dtype, device=device, resize="device", use_graphs=not args.no_graphs)
+        p.pipeline_depth = args.pipeline
+        for _ in range(4):
+            res = p.predict_batch(frames)
+        p.join()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 6
+        for _ in range(n):
+            res = p.predict_batch(frames)
+        p.join()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[label] = {"images_per_s": round(n * len(frames) / dt, 1), "measured_R": [int(o["scores"].shape[0]) for o in res]}
+        del p
+        torch.cuda.empty_cache()
+    return out
+
+
+def spawn_selftest():
+    """`--spawn-selftest`: what a rank does up to the first collective, without a GPU (gloo) - exercised by the CPU tests
+    to cover the self-launch path of `bench.py --gpus N`."""
+    import torch.distributed as dist
+    from densepose_torchscript_amd import parallel
+    rank, local_rank, world = parallel.init_distributed(backend="gloo")
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": "spawn", "world": world, "max_over_ranks": float(t.item())}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -72,8 +158,18 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-instrumented roofline pass (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the accuracy / R-sensitivity / single-frame latency extras")
+    ap.add_argument("--spawn-selftest", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    # ---- self-launch: `python bench.py --gpus N` without a launcher starts its own N ranks (fresh child processes, started
+    # before this process has made any GPU call; a process that initialised the GPU is never re-executed)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from densepose_torchscript_amd.parallel import launch_local_ranks
+        sys.exit(launch_local_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    if args.spawn_selftest:
+        return spawn_selftest()
 
     from densepose_torchscript_amd import get_config, make_synthetic_state
     from densepose_torchscript_amd import parallel
@@ -82,7 +178,8 @@ def main():
     import torch.distributed as dist
 
     rank, local_rank, world = parallel.init_distributed()
-    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -145,6 +242,16 @@ def main():
         torch.cuda.synchronize()
         step_times.append(time.perf_counter() - t0)
     flops_step = eng.flops_last
+    # single-frame latency (batch 1, synchronised per call): the number a one-image-at-a-time caller like the reference's
+    # run.py sees; the batch p50 above divided by the batch size is a throughput-style per-image figure, not this
+    single_times = []
+    if not args.no_extras:
+        for i in range(13):
+            t0 = time.perf_counter()
+            pred(frames[i % len(frames)])
+            torch.cuda.synchronize()
+            if i >= 3:
+                single_times.append(time.perf_counter() - t0)
 
     # ---- roofline of the dominant kernel: K further steps of the same workload, every conv launch bracketed by HIP events
     # on the stream it is launched on. This pass is fully serialized - one stream, no graph replay, no side stream, no
@@ -156,16 +263,20 @@ def main():
         if rank == 0:
             print(json.dumps({"value": round(args.batch * world * args.steps / elapsed, 3), "ms_per_step": round(1e3 * elapsed / args.steps, 3)}), flush=True)
         return
+    from densepose_torchscript_amd.trace import StageTrace
     pred.num_streams, eng.use_graphs, eng.overlap_decoder = 1, False, False
     for _ in range(2):
         step()
     torch.cuda.synchronize()
     eng.prof = []
+    eng.trace = StageTrace(device, roctx=False)
     t_ser = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     t_ser = (time.perf_counter() - t_ser) / args.steps
+    stages = eng.trace.summary()
+    eng.trace = None
     agg = {}
     for cls, flops, e0, e1, name, _ in eng.prof:
         a = agg.setdefault(cls, [0, 0.0, 0])
@@ -178,11 +289,13 @@ def main():
     dflops, dsec, dcalls = agg[dom]
     peak = PEAK_F32_MATRIX if args.dtype == "fp32" else PEAK_BF16_DENSE  # fp16 and bf16 MFMA share the dense peak
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
-    if os.path.exists(tpath) and args.dtype == "bf16" and args.config == "densepose_rcnn_R_50_FPN_s1x" and args.batch == 8:
-        k = json.load(open(tpath))["kernels"].get(dom + "[bf16]")
-        if k:
-            traffic = {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "source": "profiles/r1_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"}
+    for tname in ("r2_hbm_traffic.json", "r1_hbm_traffic.json"):   # newest committed PMC summary that has this kernel
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if traffic is None and os.path.exists(tpath) and args.dtype == "bf16" and args.config == "densepose_rcnn_R_50_FPN_s1x" and args.batch == 8:
+            k = json.load(open(tpath))["kernels"].get(dom + "[bf16]")
+            if k:
+                traffic = {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"],
+                           "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % tname}
     roofline = {"bound": "mfma", "kernel": dom, "achieved": round(dflops / dsec / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                 "frac": round(dflops / dsec / peak, 4), "traffic": traffic,
                 "launches_per_step": dcalls // args.steps, "avg_launch_us": round(1e6 * dsec / dcalls, 2),
@@ -193,6 +306,16 @@ def main():
                 "measured": "K event-instrumented steps on one stream (kernels alone on the chip), %.2f ms/step serialized" % (1e3 * t_ser),
                 "all_conv_classes": {c: {"tflops": round(v[0] / v[1] / 1e12, 2), "calls_per_step": v[2] // args.steps,
                                          "ms_per_step": round(1e3 * v[1] / args.steps, 3)} for c, v in agg.items()}}
+    # backbone (stem + res2..res5 + FPN, SURVEY §8d "backbone" column: 287.05 GFLOP per image for R50) over the backbone-only
+    # time of the same serialized pass: HIP events around each backbone stage on the launch stream (trace.StageTrace)
+    bb = {k: v for k, v in stages.items() if k.startswith("backbone.")}
+    if bb:
+        bms, bgf = sum(v["ms"] for v in bb.values()) / args.steps, sum(v["gflop"] for v in bb.values()) / args.steps
+        roofline["backbone"] = {"achieved": round(bgf / bms, 2), "unit": "TFLOP/s", "frac": round(bgf * 1e9 / (bms * 1e-3) / peak, 4),
+                                "ms_per_step": round(bms, 3), "alg_gflop_per_step": round(bgf, 1),
+                                "stages": {k[len("backbone."):]: {"ms": round(v["ms"] / args.steps, 3), "tflops": round(v["gflop"] / max(v["ms"], 1e-9), 1)}
+                                           for k, v in sorted(bb.items())}}
+    roofline["stage_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(stages.items()) if not k.startswith("backbone.")}
     # the 256-cout ring kernel is one source with one template instance (= one rocprofv3 kernel name) per tile height
     fam = [v for c, v in agg.items() if c.startswith("conv_ring_kernel<") and c.endswith("x256>")]
     if fam:
@@ -212,6 +335,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.dtype], "data": "synthetic",
             "p50_ms_per_img": round(1e3 * float(np.median(step_times)) / args.batch, 3),
+            "p50_note": "p50 of synchronised batch-%d steps divided by %d (throughput-style); p50_single_frame_ms is the batch-1 call latency" % (args.batch, args.batch),
+            "p50_single_frame_ms": round(1e3 * float(np.median(single_times)), 3) if single_times else None,
             "config": {"workload": "%s batch=%d/GPU %dx%d uint8 frames resident in HBM, R=%d detections/img (measured %s), synthetic seeded weights"
                                    % (args.config, args.batch, hw[0], hw[1], args.dets, dets),
                        "global_batch": args.batch * world, "parallelism": "frame-sharded dp%d, no hot-loop collective" % world,
@@ -221,9 +346,12 @@ def main():
                                       "on a side stream" if overlap else "in line", args.pipeline if pipelined else 1)},
             "roofline": roofline,
         }
+        if world == 1 and not args.no_extras:
+            result["accuracy_vs_fp32_reference"] = accuracy_vs_golden(pred, args.dtype) if (
+                args.config == "densepose_rcnn_R_50_FPN_s1x" and args.dets == 8 and hw == (800, 1333)) else None
+            result["r_sensitivity"] = r_sensitivity(args, state, frames, device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, state, hw, args.cpu_budget_s)
-            result["config"]["gpu_over_cpu"] = round(result["value"] / result["cpu_baseline"]["value"], 1)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

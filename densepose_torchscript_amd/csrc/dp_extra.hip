@@ -73,14 +73,23 @@ __global__ void resize_v_kernel(const uint8_t* __restrict__ tmp, uint8_t* __rest
   put4(dst + ((long long)blockIdx.z * 3 * oh + row) * ow, xo, ow, v);
 }
 
+// Bit-exact restatement of ATen's CPU upsample_bilinear2d (size= given, align_corners=False) as the reference's visualiser
+// calls it (visualizer.py:14-16,24-25): the vectorised CPU kernel evaluates
+//     src = fma(scale, dst + 0.5, -0.5) clamped at 0, scale = in / out in float;  i0 = min(int(src), n - 1);  l = src - i0
+//     value = fma(wy0, fma(wx0, a, wx1 * b), wy1 * fma(wx0, c, wx1 * d)),  w0 = 1 - l, w1 = l
+// (the products wx1 * b, wx1 * d and wy1 * t1 are rounded on their own). Checked bit for bit against torch's CPU kernel
+// in tests/test_oracle_ops.py::test_bilinear_restatement_is_bit_exact; contraction is switched off so that hipcc emits
+// exactly these operations and no others. (torch's kernel changes its own contraction pattern with the tensor shape -
+// outputs narrower than 63 columns, some channel counts - so on such shapes the resampled values can differ by one ulp;
+// the part index, an argmax over them, is compared bit-exactly in the tests and does not move.)
 __device__ __forceinline__ void src_index(int o, float scale, int n, int& i0, int& i1, float& l) {
-  // upsample_bilinear2d with size= given: src = max(scale * (o + 0.5) - 0.5, 0), scale = in / out (float)
-  float s = scale * ((float)o + 0.5f) - 0.5f;
+  float s = __builtin_fmaf(scale, (float)o + 0.5f, -0.5f);
   s = s < 0.f ? 0.f : s;
   i0 = (int)s;
   if (i0 > n - 1) i0 = n - 1;
   i1 = i0 + (i0 < n - 1 ? 1 : 0);
   l = s - (float)i0;
+  l = l < 0.f ? 0.f : (l > 1.f ? 1.f : l);
 }
 
 __global__ void iuv_extract_kernel(const dp_iuv_extract_params p) {
@@ -99,7 +108,9 @@ __global__ void iuv_extract_kernel(const dp_iuv_extract_params p) {
     const float hy = 1.f - ly, hx = 1.f - lx;
     const long long o00 = (long long)y0 * S + x0, o01 = (long long)y0 * S + x1, o10 = (long long)y1 * S + x0, o11 = (long long)y1 * S + x1;
     auto sample = [&](const float* base) {
-      return hy * (hx * base[o00] + lx * base[o01]) + ly * (hx * base[o10] + lx * base[o11]);
+      const float t0 = __builtin_fmaf(hx, base[o00], lx * base[o01]);
+      const float t1 = __builtin_fmaf(hx, base[o10], lx * base[o11]);
+      return __builtin_fmaf(hy, t0, ly * t1);
     };
     // coarse argmax > 0 ?
     int cbest = 0;

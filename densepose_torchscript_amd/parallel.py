@@ -36,29 +36,43 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def broadcast_tensors(tensors, src=0, bucket_bytes=256 << 20):
-    """Broadcast a fixed-order list of tensors from `src`, coalesced per dtype into few large messages
-    (xGMI links are per-peer: a handful of 100+ MB messages beats hundreds of small ones)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return
+def plan_buckets(tensors, bucket_bytes=256 << 20):
+    """Fixed-order list of tensors -> list of buckets (lists of tensors of ONE dtype, at most bucket_bytes each; a tensor
+    larger than that gets a bucket of its own). Every rank computes the same plan from the same shapes."""
     by_dtype = {}
     for t in tensors:
         by_dtype.setdefault(t.dtype, []).append(t)
-    for dt, group in by_dtype.items():
+    buckets = []
+    for group in by_dtype.values():
         bucket, size = [], 0
-        for t in group + [None]:
-            if t is not None and size + t.numel() * t.element_size() <= bucket_bytes:
-                bucket.append(t)
-                size += t.numel() * t.element_size()
-                continue
-            if bucket:
-                flat = torch.cat([b.reshape(-1) for b in bucket])
-                dist.broadcast(flat, src=src)
-                off = 0
-                for b in bucket:
-                    b.copy_(flat[off:off + b.numel()].view_as(b))
-                    off += b.numel()
-            bucket, size = ([t], t.numel() * t.element_size()) if t is not None else ([], 0)
+        for t in group:
+            nb = t.numel() * t.element_size()
+            if bucket and size + nb > bucket_bytes:
+                buckets.append(bucket)
+                bucket, size = [], 0
+            bucket.append(t)
+            size += nb
+        if bucket:
+            buckets.append(bucket)
+    return buckets
+
+
+def broadcast_tensors(tensors, src=0, bucket_bytes=256 << 20, transport=None):
+    """Broadcast a fixed-order list of tensors from `src`, coalesced per dtype into few large messages
+    (xGMI links are per-peer: a handful of 100+ MB messages beats hundreds of small ones).
+    `transport(flat)` replaces the collective on one flat buffer (tests drive the flatten / unflatten path with it);
+    the default is `dist.broadcast(flat, src)` and a no-op outside a multi-rank process group."""
+    if transport is None:
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return
+        transport = lambda flat: dist.broadcast(flat, src=src)  # noqa: E731
+    for bucket in plan_buckets(tensors, bucket_bytes):
+        flat = torch.cat([b.reshape(-1) for b in bucket])
+        transport(flat)
+        off = 0
+        for b in bucket:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
 
 
 def gather_results(local_results, dst=0):

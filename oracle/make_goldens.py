@@ -43,6 +43,17 @@ CASES = {
                            0, 21, (256, 400), False, 4),
     # BASELINE.json configs[1] geometry: 800x1333 frame, R pinned to 8
     "full_r50_s1x_800x1333": ("densepose_rcnn_R_50_FPN_s1x", ["TEST.DETECTIONS_PER_IMAGE", 8], 0, 1234, (800, 1333), False, 8),
+    # DeepLab head at its REAL geometry (densepose/config.py:177 POOLER_RESOLUTION 28; deeplab.py:33 rates 6 / 12 / 56):
+    # live d = 6 and d = 12 taps on the 28x28 ROI map, d = 56 centre-tap only; full width = GroupNorm groups of 8 (ASPP,
+    # 256 channels) and 16 (stacked convs, 512 channels) channels. BASELINE.json configs[3] at a reduced frame.
+    "full_r50_dl_p28": ("densepose_rcnn_R_50_FPN_DL_s1x",
+                        ["INPUT.MIN_SIZE_TEST", 192, "INPUT.MAX_SIZE_TEST", 320, "TEST.DETECTIONS_PER_IMAGE", 2],
+                        5, 31, (192, 300), ("dp_head_out/8",), 4),
+    # BASELINE.json configs[4] combination: R101 + DeepLab head (pool 28) on a 1080x1920 video frame (-> 749x1333);
+    # tiny channel widths keep the CPU replay short - the geometry (padding 768x1344, live dilated taps) is the real one
+    "tiny_r101_dl_p28_video": ("densepose_rcnn_R_101_FPN_DL_s1x",
+                               TINY_OPTS + ["INPUT.MIN_SIZE_TEST", 800, "INPUT.MAX_SIZE_TEST", 1333, "TEST.DETECTIONS_PER_IMAGE", 3],
+                               6, 32, (1080, 1920), ("dp_head_out/1",), 4),
 }
 
 
@@ -68,6 +79,13 @@ def run_case(name):
     model = pred.model
     cap = {}
     hooks = []
+    subset = None
+    if isinstance(stages, tuple):      # ("name/channel stride", ...): only these stage tensors, channel-subsampled
+        subset = dict((k.split("/")[0], int(k.split("/")[1])) for k in stages)
+        for nm, mod in (("dp_head_out", model.roi_heads.densepose_head), ("dp_pooled", model.roi_heads.densepose_pooler)):
+            if nm in subset:
+                hooks.append(mod.register_forward_hook((lambda n: (lambda m, i, o: cap.__setitem__(n, o)))(nm)))
+        stages = False
     if stages:
         def hook(nm):
             def fn(mod, inp, out):
@@ -98,6 +116,9 @@ def run_case(name):
     for i, r in enumerate(results):
         arrays["vis/labels_%d" % i] = r["labels"].numpy().astype(np.uint8)
         arrays["vis/uv_%d" % i] = r["uv"].numpy()
+    if subset:
+        for nm, cs in subset.items():
+            arrays["stage/" + nm] = cap[nm].numpy()[:, ::cs]
     if stages:
         for k, v in cap["features"].items():
             arrays["stage/" + k] = v.numpy()
@@ -116,7 +137,7 @@ def run_case(name):
         arrays["stage/dp_pooled"] = cap["dp_pooled"].numpy()
         arrays["stage/dp_head_out"] = cap["dp_head_out"].numpy()
     meta = dict(case=name, config=cfg_name, opts=list(opts), weight_seed=wseed, image_seed=iseed, image_hw=list(hw),
-                iuv_stride=sub, weights_sha256=state_checksum(state), torch=torch.__version__,
+                iuv_stride=sub, stage_channel_stride=(subset or {}), weights_sha256=state_checksum(state), torch=torch.__version__,
                 generator="oracle/make_goldens.py (reference imported from /root/reference)")
     arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     path = os.path.join(GOLDEN_DIR, name + ".npz")

@@ -44,7 +44,7 @@ def _assert_rows_match(boxes, scores, ref_boxes, ref_scores, score_tol=1e-4, box
 TINY = ["tiny_r50_s1x_a", "tiny_r50_s1x_b", "tiny_r50_legacy", "tiny_r101_s1x", "tiny_r50_dl", "tiny_r101_dl"]
 
 
-@pytest.mark.parametrize("name", TINY + ["full_r50_s1x_small", "full_r50_s1x_800x1333"])
+@pytest.mark.parametrize("name", TINY + ["full_r50_s1x_small", "full_r50_s1x_800x1333", "full_r50_dl_p28", "tiny_r101_dl_p28_video"])
 def test_fp32_matches_reference_golden(name):
     from oracle.ref_cpu import extract_iuv
     meta, z, cfg, pred, out = _run(name, "fp32", keep=True)
@@ -60,11 +60,19 @@ def test_fp32_matches_reference_golden(name):
         assert got.shape == z["out/" + k].shape and out[k].dtype == torch.float32
         err = np.abs(got - z["out/" + k]).max()
         assert err <= IUV_ATOL, (k, err)
-    # part-index argmax (visualizer.py:10-17), bit-exact (only available when the golden stores full-res maps)
-    if s == 1:
-        for i, (labels, uv) in enumerate(extract_iuv(out)):
-            np.testing.assert_array_equal(labels.numpy().astype(np.uint8), z["vis/labels_%d" % i])
-            np.testing.assert_allclose(uv.numpy(), z["vis/uv_%d" % i], atol=IUV_ATOL)
+    # part-index argmax (visualizer.py:10-17), bit-exact on EVERY golden: the golden's labels / uv were recorded from the
+    # reference's full-resolution maps, whatever stride its stored IUV tensors are subsampled with
+    # (resampled to the reference's integer box sizes: the boxes themselves are compared above, and a 1e-3 px difference next
+    # to an integer boundary would change the resample SIZE, which is not what this check is about)
+    vis_in = dict(out)
+    vis_in["pred_boxes"] = torch.from_numpy(z["out/pred_boxes"])
+    for i, (labels, uv) in enumerate(extract_iuv(vis_in)):
+        np.testing.assert_array_equal(labels.numpy().astype(np.uint8), z["vis/labels_%d" % i])
+        np.testing.assert_allclose(uv.numpy(), z["vis/uv_%d" % i], atol=IUV_ATOL)
+    for nm, cs in meta.get("stage_channel_stride", {}).items():   # DeepLab pool-28 cases: the head output, channel-subsampled
+        ref = z["stage/" + nm]
+        got = _nchw(pred.engine.inter[nm]).numpy()[:, ::cs][:, : ref.shape[1]]
+        assert np.abs(got - ref).max() <= 5e-4 * max(1.0, np.abs(ref).max()), nm
     if "stage/p2" in z.files:
         inter = pred.engine.inter
         for k in ("p2", "p3", "p4", "p5", "p6"):
@@ -85,9 +93,10 @@ def test_fp32_matches_reference_golden(name):
         assert np.abs(got - ref).max() <= 5e-4 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("name", ["tiny_r50_s1x_a", "tiny_r50_legacy", "tiny_r50_dl"])
+@pytest.mark.parametrize("name", ["tiny_r50_s1x_a", "tiny_r50_legacy", "tiny_r50_dl", "full_r50_s1x_small"])
 def test_fp32_matches_cpu_oracle_live(name):
-    """Same seeded inputs through the oracle on the host and the HIP path on the GPU."""
+    """Same seeded inputs through the oracle on the host and the HIP path on the GPU: every pixel of the full-resolution
+    IUV maps (the goldens of the full-width cases store a subsample), full channel width included."""
     from oracle.ref_cpu import OracleModel
     meta, z, cfg, pred, out = _run(name, "fp32")
     _, state, img = golden_case_inputs(meta)
@@ -147,21 +156,45 @@ def test_device_resize_equals_host_resize():
         assert torch.equal(out_h[k], out_d[k]), k
 
 
-@pytest.mark.parametrize("name", ["tiny_r50_s1x_a", "full_r50_s1x_small"])
-def test_bf16_mode_runs_and_is_close(name):
-    """Throughput mode (bf16 operands, fp32 accumulate): reported with its own measured tolerance (SURVEY §7 hard part 1)."""
+def _match_to_reference(out, z, s, box_tol, score_tol):
+    """Every reference detection matched to its nearest output row -> (hits, largest IUV deviation on the matched rows,
+    relative to the largest reference value of the same map)."""
+    gb, gs, rb, rs = out["pred_boxes"].numpy(), out["scores"].numpy(), z["out/pred_boxes"], z["out/scores"]
+    hits, iuv = 0, 0.0
+    for i in range(len(rb)):
+        if len(gb) == 0:
+            break
+        d = np.abs(gb - rb[i]).max(axis=1)
+        j = int(d.argmin())
+        if d[j] < box_tol and abs(gs[j] - rs[i]) < score_tol:
+            hits += 1
+            for k in IUV_KEYS:
+                ref = z["out/" + k][i]
+                iuv = max(iuv, float(np.abs(out[k][j].numpy()[:, ::s, ::s] - ref).max()) / max(float(np.abs(ref).max()), 1e-6))
+    return hits, iuv
+
+
+# bf16 has 8 significant bits and these are RANDOM-weight networks (no trained smoothness): through ~60 layers the IUV logits of
+# a matched detection move by 1 - 20 % of their range (tools/measure_bands.py prints the per-detection numbers; bench.py reports
+# the same quantities for the headline workload: 1 - 4 % there), and a borderline detection may be replaced by another one.
+# The bands below are those measurements with ~2x headroom - a regression guard for the throughput mode, not a parity claim.
+@pytest.mark.parametrize("name", ["tiny_r50_s1x_a", "full_r50_s1x_small", "full_r50_dl_p28"])
+def test_bf16_mode_stays_in_its_measured_band(name):
+    """Throughput mode (bf16 operands, fp32 accumulate) against the fp32 reference golden: the detections are found (box within
+    1.5 px, score within 0.05; at most one borderline detection may come or go) and the IUV maps of the matched detections
+    stay within 40 % of the map's range. BASELINE.json configs[3] (R_50_FPN_DL bf16) = the full_r50_dl_p28 case:
+    bf16 GroupNorm / global average pool / broadcast at the real pool-28 geometry."""
     meta, z, cfg, pred, out = _run(name, "bf16")
     for k in IUV_KEYS:
         assert torch.isfinite(out[k]).all()
     R = z["out/scores"].shape[0]
-    # detections may re-order under bf16; require the same count and that the top box matches closely when it does
     assert abs(out["scores"].shape[0] - R) <= 1
-    if out["scores"].shape[0] == R and R > 0:
-        d = np.abs(out["scores"].numpy() - z["out/scores"]).max()
-        assert d < 0.1, d
+    hits, iuv = _match_to_reference(out, z, meta["iuv_stride"], 1.5, 0.05)
+    assert hits >= R - 1, (hits, R)
+    assert iuv <= 0.4, iuv
 
 
-@pytest.mark.parametrize("name", ["tiny_r50_s1x_a", "full_r50_s1x_small", "tiny_r50_dl"])
+@pytest.mark.parametrize("name", ["tiny_r50_s1x_a", "full_r50_s1x_small", "tiny_r50_dl", "full_r50_dl_p28", "tiny_r101_dl_p28_video"])
 def test_fp16_mode_matches_reference_half_semantics(name):
     """the reference's `.half()` export (export.py:36-37, run.py:26) = IEEE-half GEMM operands. Boxes, anchors,
     decode, NMS and softmax stay fp32 here (box_regression.py:84, nms.py:20 upcast in the reference too). 10 mantissa bits
@@ -173,15 +206,10 @@ def test_fp16_mode_matches_reference_half_semantics(name):
     assert abs(out["scores"].shape[0] - R) <= 1
     # borderline detections (score next to the 0.3 threshold, degenerate boxes of the tiny random-weight cases) may come or go
     # and near-equal scores may swap places: match every reference detection to its nearest output row, allow one miss
-    gb, gs, rb, rs = out["pred_boxes"].numpy(), out["scores"].numpy(), z["out/pred_boxes"], z["out/scores"]
-    hits = 0
-    for i in range(R):
-        if len(gb) == 0:
-            break
-        d = np.abs(gb - rb[i]).max(axis=1)
-        j = int(d.argmin())
-        hits += int(d[j] < 0.5 and abs(gs[j] - rs[i]) < 0.02)   # half a pixel, 0.02 of score
+    # (tiny_r101_dl_p28_video = BASELINE.json configs[4]'s combination: R101 + DeepLab pool 28, fp16, 1080x1920 video frame)
+    hits, iuv = _match_to_reference(out, z, meta["iuv_stride"], 0.5, 0.02)   # half a pixel, 0.02 of score
     assert hits >= R - 1, (hits, R)
+    assert iuv <= 0.12, iuv     # measured: <= 0.06 of the map's range on the matched detections (bf16: up to 0.3)
 
 
 def test_missing_gpu_or_library_fails_loudly(monkeypatch):
@@ -318,8 +346,45 @@ def test_gpu_iuv_extract_matches_reference_visualizer_golden():
         ref_l, ref_uv = z["vis/labels_%d" % i], z["vis/uv_%d" % i]
         lab = r["labels"].cpu().numpy()
         assert lab.shape == ref_l.shape
-        assert (lab != ref_l).mean() <= 0.002
-        same = lab == ref_l
-        np.testing.assert_allclose(r["uv"].cpu().numpy()[:, same], ref_uv[:, same], atol=IUV_ATOL)
+        # bit-exact part index: dp_iuv_extract restates the CPU bilinear kernel operation by operation, and the fp32 maps it
+        # reads agree with the reference's to ~1e-5, far inside the margin between the two largest resampled logits here
+        np.testing.assert_array_equal(lab, ref_l)
+        np.testing.assert_allclose(r["uv"].cpu().numpy(), ref_uv, atol=IUV_ATOL)
     img = iuv_image(results, xywh, int(out["image_size"][0]), int(out["image_size"][1]))
     assert img.shape == (3, int(out["image_size"][0]), int(out["image_size"][1])) and img.dtype == np.uint8
+
+
+@pytest.mark.parametrize("name,dtype", [("tiny_r50_s1x_a", "fp32"), ("tiny_r50_s1x_a", "bf16"), ("tiny_r50_dl", "bf16"), ("tiny_r101_dl", "fp16")])
+def test_replica_built_from_broadcast_weights_equals_rank0(name, dtype):
+    """N ranks x the same frames == 1 rank. Rank 0 packs the real weights; every other rank builds its engine from
+    a zeros / ones state (bench.py) and receives `PackedModel.parameter_tensors()` through parallel.broadcast_tensors.
+    Here the collective is replaced by a copy of rank 0's flat buckets (the flatten / unflatten code is the real one), and the
+    replica's outputs must be bit-identical to rank 0's."""
+    from densepose_torchscript_amd import parallel
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    from densepose_torchscript_amd.weights import param_shapes
+    meta, z = load_golden(name)
+    cfg, state, img = golden_case_inputs(meta)
+    rank0 = DensePosePredictor(cfg, state, dtype=dtype)
+    blank = {k: np.zeros(s, dtype=np.float32) for k, s in param_shapes(cfg).items()}
+    for k in blank:
+        if k.endswith("running_var"):
+            blank[k] += 1.0
+    replica = DensePosePredictor(cfg, blank, dtype=dtype)
+    src, dst = rank0.engine.model.parameter_tensors(), replica.engine.model.parameter_tensors()
+    assert [(t.shape, t.dtype) for t in src] == [(t.shape, t.dtype) for t in dst]
+    assert any(not torch.equal(a, b) for a, b in zip(src, dst))       # the replica really starts from different weights
+    bucket = 1 << 16                                                     # small buckets: many messages, tensors > one bucket too
+    wire = [torch.cat([b.reshape(-1) for b in bk]) for bk in parallel.plan_buckets(src, bucket)]
+    parallel.broadcast_tensors(dst, src=0, bucket_bytes=bucket, transport=lambda flat: flat.copy_(wire.pop(0)))
+    assert not wire
+    for a, b in zip(src, dst):
+        assert torch.equal(a, b)
+    rng = np.random.default_rng(3)
+    frames = [torch.from_numpy(img)] + [torch.from_numpy(rng.integers(0, 256, img.shape, dtype=np.uint8)) for _ in range(2)]
+    want, got = rank0.predict_batch(frames), replica.predict_batch(frames)
+    torch.cuda.synchronize()
+    assert sum(int(w["scores"].shape[0]) for w in want) > 0
+    for w, g in zip(want, got):
+        for k in w:
+            assert torch.equal(w[k].cpu(), g[k].cpu()), (name, dtype, k)

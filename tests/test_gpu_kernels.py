@@ -603,6 +603,44 @@ def test_box_decode_and_groupnorm_gap(eng):
     assert torch.equal(bc[..., Cc:].cpu(), pooled.cpu()[:, None, :].expand(Rr, HW, Cc))
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(3, 28, 256, 1280, 512), (2, 28, 512, 512, 0), (5, 7, 64, 128, 64), (2, 1, 256, 256, 0)])
+def test_groupnorm_gap_broadcast_all_dtypes(eng, dt, shape):
+    """DeepLab head pieces (deeplab.py:45,90,97,109) in every storage type at the real geometry: 28x28 ROI maps, GroupNorm(32)
+    over 256 channels (groups of 8, written into a slice of the 1280-channel ASPP concat) and over 512 channels (groups of
+    16), the 1x1 pooled branch (HW = 1). Statistics are fp32 whatever the storage type; the result is rounded once."""
+    from densepose_torchscript_amd import lib as L
+    e = eng[dt]
+    Rr, P, Cc, cstride, coff = shape
+    HW = P * P
+    g = torch.Generator().manual_seed(Rr * 100 + P + Cc)
+    x = torch.randn((Rr, Cc, P, P), generator=g) * 1.5 + 0.3
+    gamma, beta = torch.randn((Cc,), generator=g), torch.randn((Cc,), generator=g)
+    if dt != "fp32":
+        x = _round(x, dt)
+    ulp = {"fp32": 2.0 ** -22, "bf16": 2.0 ** -8, "fp16": 2.0 ** -11}[dt]
+    buf = torch.zeros((Rr, HW, cstride), dtype=e.tdt, device=e.device)
+    buf[..., coff:coff + Cc] = x.permute(0, 2, 3, 1).reshape(Rr, HW, Cc).to(e.tdt).to(e.device)
+    q = L.GroupNormParams()
+    gd, bd = gamma.to(e.device), beta.to(e.device)
+    q.x, q.R, q.HW, q.C, q.c_stride, q.c_off, q.groups = buf.data_ptr(), Rr, HW, Cc, cstride, coff, 32
+    q.gamma, q.beta, q.eps, q.relu, q.dtype = gd.data_ptr(), bd.data_ptr(), 1e-5, 1, e.dt
+    L.check(e.lib.dp_groupnorm_relu_nhwc(C.byref(q), e._stream()))
+    ref = F.relu(F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5)).permute(0, 2, 3, 1).reshape(Rr, HW, Cc)
+    got = buf[..., coff:coff + Cc].double().cpu()
+    assert bool(((got - ref).abs() <= ulp * ref.abs() + 3e-5).all()), float((got - ref).abs().max())
+    other = torch.cat([buf[..., :coff], buf[..., coff + Cc:]], dim=-1)
+    assert other.numel() == 0 or float(other.float().abs().max()) == 0.0       # channels outside the slice are untouched
+    xin = x.permute(0, 2, 3, 1).contiguous().to(e.tdt).to(e.device)
+    pooled = torch.empty((Rr, Cc), dtype=e.tdt, device=e.device)
+    assert e.lib.dp_global_avgpool_nhwc(xin.data_ptr(), pooled.data_ptr(), Rr, HW, Cc, e.dt, e._stream()) == 0
+    mref = x.double().mean(dim=(2, 3))
+    assert bool(((pooled.double().cpu() - mref).abs() <= ulp * mref.abs() + 1e-5).all())
+    bc = torch.zeros((Rr, HW, cstride), dtype=e.tdt, device=e.device)
+    assert e.lib.dp_broadcast_hw_nhwc(pooled.data_ptr(), bc.data_ptr(), Rr, HW, Cc, cstride, coff, e.dt, e._stream()) == 0
+    assert torch.equal(bc[..., coff:coff + Cc].cpu(), pooled.cpu()[:, None, :].expand(Rr, HW, Cc))
+
+
 def test_resize_and_iuv_extract(eng):
     from densepose_torchscript_amd import lib as L
     from densepose_torchscript_amd.resize import resize_u8_device
@@ -656,7 +694,11 @@ def test_resize_and_iuv_extract(eng):
         w, h = int(xywh[r, 2]), int(xywh[r, 3])
         lab = labels[offs[r]: offs[r] + h * w].cpu().view(h, w)
         u_ = uv[2 * offs[r]: 2 * offs[r] + 2 * h * w].cpu().view(2, h, w)
-        mism = (lab.long() != ref[r][0]).float().mean().item()
-        assert mism <= 0.002, mism  # argmax flips only where two bilinear samples tie within 1 ulp
-        same = lab.long() == ref[r][0]
-        assert torch.allclose(u_[:, same], ref[r][1][:, same], atol=1e-5)
+        # part index: bit-exact. The kernel restates ATen's CPU bilinear arithmetic operation by operation (dp_extra.hip,
+        # src_index / sample); torch's CPU kernel itself switches its FMA contraction pattern with the tensor shape (output
+        # narrower than 63 columns, channel count: measured in this container), so the resampled VALUES can sit one ulp
+        # apart on such shapes - the argmax over them does not move
+        assert torch.equal(lab.long(), ref[r][0]), (r, int((lab.long() != ref[r][0]).sum()))
+        assert torch.allclose(u_, ref[r][1], atol=1e-6, rtol=0), r
+        if w >= 63:
+            assert torch.equal(u_, ref[r][1]), r

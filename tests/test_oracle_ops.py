@@ -105,3 +105,36 @@ def test_c_backend_equals_numpy_backend_bit_for_bit():
     scores = torch.from_numpy(rng.random(200).astype(np.float32))
     for thr in (0.3, 0.5, 0.7):
         assert torch.equal(ops_ref.nms(boxes, scores, thr, backend="c"), ops_ref.nms(boxes, scores, thr, backend="numpy"))
+
+
+def test_bilinear_restatement_is_bit_exact():
+    """The arithmetic dp_iuv_extract implements for the visualiser's F.interpolate(bilinear, align_corners=False)
+    (visualizer.py:14-16,24-25): src = fma(scale, dst + 0.5, -0.5), value = fma(wy0, fma(wx0, a, wx1*b), wy1 * fma(wx0, c, wx1*d)).
+    numpy float64 products of float32 operands are exact, so fma() below rounds once like the hardware instruction;
+    the result must equal torch's CPU kernel bit for bit (that is what the -m gpu tests then hold the HIP kernel to)."""
+    import torch
+    import torch.nn.functional as F
+    f32 = np.float32
+
+    def fma(p, q, r):
+        return (np.asarray(p, dtype=np.float64) * np.asarray(q, dtype=np.float64) + np.asarray(r, dtype=np.float64)).astype(np.float32)
+
+    def axis(n_out, n_in):
+        scale = f32(n_in) / f32(n_out)
+        src = np.maximum(fma(scale, (np.arange(n_out, dtype=np.float32) + f32(0.5)).astype(np.float32), f32(-0.5)), f32(0))
+        i0 = np.minimum(src.astype(np.int64), n_in - 1)
+        lam = np.clip(src - i0.astype(np.float32), 0, 1).astype(np.float32)
+        return i0, np.minimum(i0 + 1, n_in - 1), (f32(1) - lam).astype(np.float32), lam
+
+    x = torch.randn((1, 5, 112, 112), generator=torch.Generator().manual_seed(0))
+    X = x.numpy()[0]
+    for h, w in ((57, 83), (200, 131), (13, 300), (112, 112), (1, 1), (300, 7)):
+        ref = F.interpolate(x, (h, w), mode="bilinear", align_corners=False).numpy()[0]
+        y0, y1, wy0, wy1 = axis(h, 112)
+        x0, x1, wx0, wx1 = axis(w, 112)
+        a, b, c, d = X[:, y0][:, :, x0], X[:, y0][:, :, x1], X[:, y1][:, :, x0], X[:, y1][:, :, x1]
+        WX0, WX1, WY0, WY1 = wx0[None, None, :], wx1[None, None, :], wy0[None, :, None], wy1[None, :, None]
+        t0 = fma(WX0, a, (WX1 * b).astype(np.float32))
+        t1 = fma(WX0, c, (WX1 * d).astype(np.float32))
+        got = fma(WY0, t0, (WY1 * t1).astype(np.float32))
+        assert np.array_equal(got, ref), (h, w, float(np.abs(got - ref).max()))

@@ -75,3 +75,41 @@ def test_shard_range_properties():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_self_launch_spawns_ranks_over_gloo():
+    """`python bench.py --gpus 2` with no launcher starts its own two ranks (RANK / WORLD_SIZE / MASTER_* per child, rank 0
+    owns stdout); `--spawn-selftest` makes each rank stop after the first collective, so the path runs without a GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--spawn-selftest"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()          # ONE JSON line, printed by rank 0
+    rec = json.loads(lines[0])
+    assert rec["world"] == 2 and rec["max_over_ranks"] == 2.0   # MAX over ranks reached rank 0
+
+
+def test_bench_self_launch_propagates_rank_failure():
+    """Without a GPU every rank of the real benchmark exits with 'needs a GPU'; the parent must return non-zero (and must
+    not hang waiting for a rank that lost its peer)."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-container check")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert p.returncode != 0
+    assert b"needs a GPU" in p.stderr + p.stdout
+
+
+def test_launch_local_ranks_stops_peers_when_one_rank_fails(tmp_path):
+    from densepose_torchscript_amd.parallel import launch_local_ranks
+    script = tmp_path / "w.py"
+    script.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(60)\n")
+    import time
+    t0 = time.time()
+    rc = launch_local_ranks([str(script)], 3)
+    assert rc == 7 and time.time() - t0 < 30
