@@ -84,12 +84,23 @@ class ModelConfig:
                     v = literal_eval(v)
                 except (ValueError, SyntaxError):
                     pass
+            if k in _FIXED_KEYS:
+                # semantics the kernels hard-wire: accepted only with the value they implement, never silently ignored
+                allowed = _FIXED_KEYS[k]
+                if v not in allowed:
+                    raise ValueError("%s = %r is not supported by the MI355X path (implemented: %s)"
+                                     % (k, v, " / ".join(repr(a) for a in allowed)))
+                continue
             if k not in _KEYMAP:
                 if k in _IGNORED_KEYS or k.split(".")[0] in ("SOLVER", "DATASETS", "DATALOADER"):
                     continue
                 raise KeyError("unsupported config key for the inference path: " + k)
             field, conv = _KEYMAP[k]
             kw[field] = conv(v)
+        if kw.get("dp_head", self.dp_head) not in ("DensePoseV1ConvXHead", "DensePoseDeepLabHead"):
+            raise ValueError("MODEL.ROI_DENSEPOSE_HEAD.NAME = %r is not supported (DensePoseV1ConvXHead / DensePoseDeepLabHead)" % kw["dp_head"])
+        if kw.get("input_format", self.input_format) not in ("BGR", "RGB"):
+            raise ValueError("INPUT.FORMAT = %r is not supported (BGR / RGB)" % kw["input_format"])
         return dataclasses.replace(self, **kw)
 
     @staticmethod
@@ -142,16 +153,56 @@ _KEYMAP = {
     "MODEL.ROI_DENSEPOSE_HEAD.NUM_PATCHES": ("dp_patches", int),
 }
 
-# keys that appear in the BASELINE yamls but do not change the inference path
+# Keys whose semantics are hard-wired in the kernels / the engine: a yaml or override may state them, but only with the value
+# that is implemented - anything else raises instead of being computed with the wrong semantics (e.g. the reference's own
+# default POOLER_TYPE is ROIAlignV2 = aligned=True, densepose/config.py:176; the BASELINE yamls set ROIAlign, Base-...yaml:33,36).
+_FIXED_KEYS = {
+    "MODEL.META_ARCHITECTURE": ("GeneralizedRCNN",),
+    "MODEL.BACKBONE.NAME": ("build_resnet_fpn_backbone",),
+    "MODEL.RESNETS.OUT_FEATURES": (["res2", "res3", "res4", "res5"], ("res2", "res3", "res4", "res5")),
+    "MODEL.RESNETS.STRIDE_IN_1X1": (True,),
+    "MODEL.RESNETS.NUM_GROUPS": (1,),
+    "MODEL.RESNETS.RES5_DILATION": (1,),
+    "MODEL.RESNETS.NORM": ("FrozenBN",),
+    "MODEL.FPN.IN_FEATURES": (["res2", "res3", "res4", "res5"], ("res2", "res3", "res4", "res5")),
+    "MODEL.FPN.NORM": ("",),
+    "MODEL.FPN.FUSE_TYPE": ("sum",),
+    "MODEL.RPN.IN_FEATURES": (["p2", "p3", "p4", "p5", "p6"], ("p2", "p3", "p4", "p5", "p6")),
+    "MODEL.RPN.HEAD_NAME": ("StandardRPNHead",),
+    "MODEL.PROPOSAL_GENERATOR.NAME": ("RPN",),
+    "MODEL.PROPOSAL_GENERATOR.MIN_SIZE": (0,),
+    "MODEL.ANCHOR_GENERATOR.OFFSET": (0.0, 0),
+    "MODEL.DENSEPOSE_ON": (True,),
+    "MODEL.MASK_ON": (False,),
+    "MODEL.KEYPOINT_ON": (False,),
+    "MODEL.ROI_HEADS.NAME": ("DensePoseROIHeads",),
+    "MODEL.ROI_HEADS.IN_FEATURES": (["p2", "p3", "p4", "p5"], ("p2", "p3", "p4", "p5")),
+    "MODEL.ROI_HEADS.NUM_CLASSES": (1,),
+    "MODEL.ROI_BOX_HEAD.NAME": ("FastRCNNConvFCHead",),
+    "MODEL.ROI_BOX_HEAD.POOLER_TYPE": ("ROIAlign",),           # aligned=False (poolers.py:149-155)
+    "MODEL.ROI_BOX_HEAD.NUM_CONV": (0,),
+    "MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG": (False,),
+    "MODEL.ROI_DENSEPOSE_HEAD.POOLER_TYPE": ("ROIAlign",),
+    "MODEL.ROI_DENSEPOSE_HEAD.DECONV_KERNEL": (4,),            # chart.py:45-59: the four sub-pixel 2x2 convolutions
+    "MODEL.ROI_DENSEPOSE_HEAD.UP_SCALE": (2,),                 # chart.py:72-74: bilinear x2
+    "MODEL.ROI_DENSEPOSE_HEAD.CONV_HEAD_KERNEL": (3,),
+    "MODEL.ROI_DENSEPOSE_HEAD.PREDICTOR_NAME": ("DensePoseChartWithConfidencePredictor", "DensePoseChartPredictor"),
+    "MODEL.ROI_DENSEPOSE_HEAD.DECODER_COMMON_STRIDE": (4,),
+    "MODEL.ROI_DENSEPOSE_HEAD.DECODER_NORM": ("",),
+    "MODEL.ROI_DENSEPOSE_HEAD.UV_CONFIDENCE.ENABLED": (False,),   # confidence heads add output keys: out of scope
+    "MODEL.ROI_DENSEPOSE_HEAD.SEGM_CONFIDENCE.ENABLED": (False,),
+    "MODEL.ROI_DENSEPOSE_HEAD.DEEPLAB.NORM": ("GN",),
+    "MODEL.ROI_DENSEPOSE_HEAD.DEEPLAB.NONLOCAL_ON": (0, False),
+}
+
+# keys that appear in the reference yamls but do not change the inference path (training-only or bookkeeping)
 _IGNORED_KEYS = {
-    "VERSION", "_BASE_", "MODEL.META_ARCHITECTURE", "MODEL.BACKBONE.NAME", "MODEL.RESNETS.OUT_FEATURES",
-    "MODEL.FPN.IN_FEATURES", "MODEL.RPN.IN_FEATURES", "MODEL.RPN.PRE_NMS_TOPK_TRAIN",
-    "MODEL.RPN.POST_NMS_TOPK_TRAIN", "MODEL.DENSEPOSE_ON", "MODEL.ROI_HEADS.NAME",
-    "MODEL.ROI_HEADS.IN_FEATURES", "MODEL.ROI_HEADS.NUM_CLASSES", "MODEL.ROI_BOX_HEAD.NAME",
-    "MODEL.ROI_BOX_HEAD.POOLER_TYPE", "MODEL.ROI_DENSEPOSE_HEAD.POOLER_TYPE", "MODEL.WEIGHTS",
+    "VERSION", "_BASE_", "MODEL.RPN.PRE_NMS_TOPK_TRAIN", "MODEL.RPN.POST_NMS_TOPK_TRAIN", "MODEL.WEIGHTS",
     "INPUT.MIN_SIZE_TRAIN", "MODEL.ROI_DENSEPOSE_HEAD.HEATMAP_SIZE",
     "MODEL.ROI_DENSEPOSE_HEAD.INDEX_WEIGHTS", "MODEL.ROI_DENSEPOSE_HEAD.PART_WEIGHTS",
     "MODEL.ROI_DENSEPOSE_HEAD.POINT_REGRESSION_WEIGHTS", "MODEL.DEVICE",
+    "MODEL.ROI_DENSEPOSE_HEAD.UV_CONFIDENCE.EPSILON", "MODEL.ROI_DENSEPOSE_HEAD.UV_CONFIDENCE.TYPE",
+    "MODEL.ROI_DENSEPOSE_HEAD.SEGM_CONFIDENCE.EPSILON", "MODEL.ROI_DENSEPOSE_HEAD.COARSE_SEGM_TRAINED_BY_MASKS",
 }
 
 

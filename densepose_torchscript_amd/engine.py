@@ -17,7 +17,14 @@ from .pack import PackedModel, round_up
 from .weights import decoder_layout, resnet_blocks
 
 FPN_STRIDES = (4, 8, 16, 32, 64)
-CPU_TRICK_MAX_NUMEL = 4000  # torchvision batched_nms strategy switch on the reference's CPU path
+# torchvision 0.16.2 batched_nms switches from the coordinate-offset trick to the per-class loop above this many box
+# ELEMENTS: 4000 where the reference runs on the CPU (what the goldens were recorded with), 20000 in its CUDA mode
+# (run.py:22-29). At 800x1333 the RPN feeds 4 x 4819 = 19276 elements: per-level loop on the CPU, trick on CUDA; the two
+# differ only where an IoU sits within rounding of the threshold. Engine.nms_reference picks the one to reproduce.
+NMS_TRICK_MAX_NUMEL = {"cpu": 4000, "cuda": 20000}
+MAX_GRAPHS = 4   # captured HIP graphs kept per engine (each pins the activations of its shape): least recently used is dropped
+
+_engine_device = None   # the one device this process drives (one process per GPU: DESIGN.md §5)
 
 
 def _ptr(t):
@@ -39,6 +46,18 @@ class Engine:
         self.lib = L.load()
         self.cfg = cfg
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        # One process drives ONE GPU (frames shard over processes, parallel.py): the library caches per-kernel attributes and
+        # the CU count per process, and events / graph capture follow the current device. A second engine on another device
+        # in the same process would silently read stale detection counts - refuse it instead.
+        global _engine_device
+        if _engine_device is None:
+            _engine_device = self.device
+        elif _engine_device != self.device:
+            raise L.DensePoseHipError("this process already drives %s; start one process per GPU (parallel.launch_local_ranks) "
+                                      "instead of a second engine on %s" % (_engine_device, self.device))
+        torch.cuda.set_device(self.device)
         if dtype not in L.DTYPES:
             raise ValueError("dtype must be one of %s" % sorted(L.DTYPES))
         self.dt = L.DTYPES[dtype]
@@ -58,6 +77,7 @@ class Engine:
         self.flops_last = 0
         self.prof = None  # list of (kernel class, algorithmic flops, start event, end event) when profiling
         self.use_graphs = False
+        self.nms_reference = "cpu"    # "cpu" | "cuda": which torchvision batched_nms strategy switch to reproduce (see above)
         self.fuse_bottleneck = True   # res2 blocks: conv2 -> conv3 -> next conv1 in one launch (bottleneck_tail)
         self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
         self._side_streams = {}
@@ -117,9 +137,9 @@ class Engine:
         flops = 2 * layer.macs_per_pixel * N * Ho * Wo
         if self.prof is not None and N * Ho * Wo > 0:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0.record(torch.cuda.current_stream(self.device))
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
-            e1.record()
+            e1.record(torch.cuda.current_stream(self.device))
             cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_ring_kernel<256x256>", "conv_ring_kernel<128x128>", "conv_ring2_kernel<256x128>", "conv1x1_stream_kernel")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
             if cls.startswith("conv_ring_kernel<"):   # one template instance (= one rocprofv3 kernel name) per tile height
                 cls = "conv_ring_kernel<%dx%s" % (self.lib.dp_conv2d_tile_rows(C.byref(p)), cls.split("x")[1])
@@ -285,7 +305,7 @@ class Engine:
         ws = self._empty((self.lib.dp_nms_workspace_bytes(n, slots),), torch.uint8)
         p = L.NmsParams()
         p.boxes, p.scores, p.group, p.valid = boxes.data_ptr(), scores.data_ptr(), group.data_ptr(), valid.data_ptr()
-        p.n_img, p.n_slots, p.iou_thr, p.max_out, p.trick_max_numel = n, slots, thr, max_out, CPU_TRICK_MAX_NUMEL
+        p.n_img, p.n_slots, p.iou_thr, p.max_out, p.trick_max_numel = n, slots, thr, max_out, NMS_TRICK_MAX_NUMEL[self.nms_reference]
         p.out_boxes, p.out_scores, p.out_index, p.out_count = out_boxes.data_ptr(), out_scores.data_ptr(), out_index.data_ptr(), out_count.data_ptr()
         p.workspace = ws.data_ptr()
         L.check(self.lib.dp_batched_nms(C.byref(p), self._stream()), "dp_batched_nms")
@@ -508,9 +528,15 @@ class Engine:
             pinned = self._pinned_counts(("eager", slot), n)
             pinned.copy_(st["det_counts"], non_blocking=True)
         else:
-            key = (tuple(images_u8.shape), slot)
-            entry = self._graphs.get(key)
+            # everything that changes the captured launch sequence is part of the key
+            key = (tuple(images_u8.shape), slot, self.overlap_decoder, self.fuse_bottleneck, self.nms_reference)
+            entry = self._graphs.pop(key, None)
             if entry is None:
+                while len(self._graphs) >= MAX_GRAPHS:      # drop the least recently used graph and its memory pool
+                    torch.cuda.synchronize(self.device)     # (rare: a new input geometry) its last replay may still be running
+                    old = self._graphs.pop(next(iter(self._graphs)))
+                    self._pinned.pop(old[5], None)
+                    del old
                 static_in = images_u8.clone()
                 self._phase_a(static_in)            # eager warm-up: one-time attribute / table initialisation outside capture
                 torch.cuda.current_stream(self.device).synchronize()
@@ -520,16 +546,16 @@ class Engine:
                 with torch.cuda.graph(graph):
                     st = self._phase_a(static_in)
                     pinned.copy_(st["det_counts"], non_blocking=True)
-                entry = (graph, static_in, st, pinned, self.flops_last - flops0)
-                self._graphs[key] = entry
+                entry = (graph, static_in, st, pinned, self.flops_last - flops0, key)
                 self.flops_last = flops0
-            graph, static_in, st, pinned, flops = entry
+            self._graphs[key] = entry                       # (re-)inserted last = most recently used
+            graph, static_in, st, pinned, flops, _ = entry
             static_in.copy_(images_u8, non_blocking=True)
             graph.replay()
             self.flops_last += flops
             st = dict(st)
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(torch.cuda.current_stream(self.device))
         st["counts_pinned"], st["counts_event"] = pinned, ev
         return st
 

@@ -22,7 +22,7 @@ from .weights import check_state, load_checkpoint
 
 class DensePosePredictor:
     def __init__(self, cfg, weights, dtype="bf16", device="cuda:0", resize="host", num_streams=1, use_graphs=False, check_keep=False,
-                 pipeline_depth=1):
+                 pipeline_depth=1, nms_reference="cpu"):
         """cfg: ModelConfig | variant name | yaml path. weights: path to .pkl/.pth or a canonical state dict."""
         if not isinstance(cfg, ModelConfig):
             cfg = get_config(cfg)
@@ -38,6 +38,12 @@ class DensePosePredictor:
         self.resize_mode = resize  # "host": torch CPU uint8 kernel exactly as the reference (Q4) ; "device": HIP kernel
         self.num_streams = num_streams  # sub-batches of a batch run concurrently on this many HIP streams
         self.engine.use_graphs = use_graphs  # replay the static part of the path (backbone .. detection select) as a HIP graph
+        # HIP graphs are for fixed-geometry streams (a video, a benchmark): one graph per (batch shape, lane), at most
+        # engine.MAX_GRAPHS kept (least recently used dropped); a stream of ever-changing frame sizes should run eagerly.
+        # nms_reference: "cpu" reproduces torchvision's batched_nms strategy switch of the reference's CPU mode (what the golden
+        # vectors were recorded with; default), "cuda" the one of its CUDA mode (run.py:22-29) - see engine.NMS_TRICK_MAX_NUMEL
+        assert nms_reference in ("cpu", "cuda"), nms_reference
+        self.engine.nms_reference = nms_reference
         # postprocessing.py:51 drops boxes with negative extent after rescaling. That cannot happen on this path: decoded
         # boxes have w = exp(dw) * w_src >= 0 (box_regression.py:104-105), clipping and the positive rescale are monotonic,
         # non-finite boxes were filtered before NMS. The flags are still computed on the device; reading them back costs a
@@ -47,6 +53,7 @@ class DensePosePredictor:
         # (see predict_batch / join); 1 = every call is ordered on the caller's stream like the reference's module call
         self.pipeline_depth = pipeline_depth
         self._lanes, self._next_lane = [], 0
+        self._last_done = []   # completion events of the most recent predict_batch call (one per frame group)
 
     # -- defaults.py:76-89 ---------------------------------------------------------------------------------
     def _to_chw(self, original_image, bgr):
@@ -94,6 +101,7 @@ class DensePosePredictor:
             groups.setdefault((tuple(c.shape), c.stride(0) == 1 and c.stride(2) == 3), []).append(i)
         out = [None] * len(images)
         cur = torch.cuda.current_stream(self.device)
+        self._last_done = []
         for idxs in groups.values():
             lane, stream = 0, cur
             if self.pipeline_depth > 1:
@@ -115,6 +123,9 @@ class DensePosePredictor:
                 if self.check_keep:
                     res = self.engine.apply_keep_filter(res)
             if stream is not cur:
+                done = torch.cuda.Event()
+                done.record(stream)
+                self._last_done.append(done)
                 for r in res:
                     for t in r.values():
                         if t.is_cuda:
@@ -128,3 +139,14 @@ class DensePosePredictor:
         cur = torch.cuda.current_stream(self.device)
         for s in self._lanes:
             cur.wait_stream(s)
+
+    def completion(self):
+        """Handle for the batch the most recent predict_batch call submitted: pass it to wait() to make the caller's stream wait
+        for THAT batch only - unlike join(), later batches on the other lanes keep running (run.py: post-processing of batch
+        i-1 beside batch i)."""
+        return list(self._last_done)
+
+    def wait(self, handle):
+        cur = torch.cuda.current_stream(self.device)
+        for ev in handle:
+            cur.wait_event(ev)

@@ -191,15 +191,17 @@ def _nms_numpy(boxes, scores, iou_threshold):
     return torch.as_tensor(np.asarray(keep, dtype=np.int64))
 
 
-def _cpu_uses_coordinate_trick(boxes):
+def _uses_coordinate_trick(boxes, trick_max_numel):
     # torchvision/ops/boxes.py: vanilla loop iff numel > 4000 on CPU (20000 on GPU)
-    return not (boxes.numel() > 4000)
+    return not (boxes.numel() > trick_max_numel)
 
 
-def batched_nms(boxes, scores, idxs, iou_threshold):
+def batched_nms(boxes, scores, idxs, iou_threshold, trick_max_numel=4000):
+    """trick_max_numel: torchvision's strategy switch - 4000 where the reference runs on the CPU (the goldens), 20000 for its
+    CUDA mode (run.py:22-29)."""
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64)
-    if _cpu_uses_coordinate_trick(boxes):
+    if _uses_coordinate_trick(boxes, trick_max_numel):
         max_coordinate = boxes.max()
         offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
         boxes_for_nms = boxes + offsets[:, None]

@@ -31,8 +31,11 @@ def _t(a):
 
 
 class OracleModel:
-    def __init__(self, cfg, state):
+    def __init__(self, cfg, state, nms_trick_max_numel=4000):
         self.cfg = cfg
+        # torchvision batched_nms strategy switch: 4000 box elements where the reference runs on the CPU (default; what the
+        # goldens were recorded with), 20000 restates its CUDA mode (run.py:22-29)
+        self.nms_trick_max_numel = nms_trick_max_numel
         self.w = OrderedDict((k, _t(v)) for k, v in state.items())
         self.pixel_mean = torch.tensor(cfg.pixel_mean, dtype=torch.float32).view(-1, 1, 1)
         self.pixel_std = torch.tensor(cfg.pixel_std, dtype=torch.float32).view(-1, 1, 1)
@@ -210,7 +213,7 @@ class OracleModel:
         keep = self.nonempty(boxes, 0.0)
         if int(keep.sum()) != len(boxes):
             boxes, scores, lvl = boxes[keep], scores[keep], lvl[keep]
-        keep = ops_ref.batched_nms(boxes.float(), scores, lvl, cfg.rpn_nms_thresh)
+        keep = ops_ref.batched_nms(boxes.float(), scores, lvl, cfg.rpn_nms_thresh, self.nms_trick_max_numel)
         keep = keep[: cfg.rpn_post_topk]
         res = {"image_size": image_size, "proposal_boxes": boxes[keep], "objectness_logits": scores[keep]}
         if want_all:
@@ -270,7 +273,7 @@ class OracleModel:
         inds = mask.nonzero()
         bsel = boxes3[inds[:, 0], 0]
         ssel = sc[mask]
-        keep = ops_ref.batched_nms(bsel.float(), ssel, inds[:, 1], cfg.nms_thresh)
+        keep = ops_ref.batched_nms(bsel.float(), ssel, inds[:, 1], cfg.nms_thresh, self.nms_trick_max_numel)
         if cfg.dets_per_image >= 0:
             keep = keep[: cfg.dets_per_image]
         res = {"image_size": proposals["image_size"], "pred_boxes": bsel[keep], "scores": ssel[keep],

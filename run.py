@@ -34,8 +34,8 @@ def run_frames(predictor, frames, batch):
     def drain(keep):
         nonlocal n_det
         while len(pending) > keep:
-            outs = pending.pop(0)
-            predictor.join()        # make this stream wait for the lane that produced them
+            outs, done = pending.pop(0)
+            predictor.wait(done)    # this stream waits for the batch it consumes only; the newer batch keeps its lane busy
             for o in outs:
                 results, xywh = extract_iuv(o)
                 h, w = [int(v) for v in o["image_size"]]
@@ -44,7 +44,7 @@ def run_frames(predictor, frames, batch):
 
     for i in range(0, len(frames), batch):
         chunk = [torch.from_numpy(f).to(predictor.device, non_blocking=True) for f in frames[i:i + batch]]
-        pending.append(predictor.predict_batch(chunk))
+        pending.append((predictor.predict_batch(chunk), predictor.completion()))
         drain(1)                    # post-process batch i-1 while batch i runs
     drain(0)
     return np.stack(iuvs), n_det

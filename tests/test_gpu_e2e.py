@@ -108,6 +108,29 @@ def test_fp32_matches_cpu_oracle_live(name):
         assert (out[k] - ref[k]).abs().max().item() <= IUV_ATOL, k
 
 
+def test_cuda_reference_nms_strategy_matches_oracle():
+    """nms_reference="cuda": torchvision's batched_nms switches strategy at 20000 box elements in the reference's CUDA mode
+    (run.py:22-29) instead of 4000 on the CPU. full_r50_s1x_small feeds the RPN NMS ~3400 boxes = ~13.5k elements: the
+    per-level loop under "cpu", the coordinate-offset trick under "cuda". The oracle restates both (nms_trick_max_numel)."""
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    from oracle.ref_cpu import OracleModel
+    meta, z = load_golden("full_r50_s1x_small")
+    cfg, state, img = golden_case_inputs(meta)
+    pred = DensePosePredictor(cfg, state, dtype="fp32", nms_reference="cuda", check_keep=True)
+    pred.engine.keep_intermediates = True
+    out = {k: v.cpu() for k, v in pred(torch.from_numpy(img)).items()}
+    _, _, pcounts = pred.engine.inter["proposals"]
+    cb, cs, cl, cv = pred.engine.inter["cand"]
+    n_valid = int(cv[0].sum())
+    assert 4000 < 4 * n_valid <= 20000, n_valid          # between the two switches: the two references take different strategies
+    ref = OracleModel(cfg, state, nms_trick_max_numel=20000)(torch.from_numpy(img))
+    assert out["scores"].shape == ref["scores"].shape
+    np.testing.assert_allclose(out["pred_boxes"].numpy(), ref["pred_boxes"].numpy(), atol=2e-3, rtol=1e-5)
+    np.testing.assert_allclose(out["scores"].numpy(), ref["scores"].numpy(), atol=1e-5)
+    for k in IUV_KEYS:
+        assert (out[k] - ref[k]).abs().max().item() <= IUV_ATOL, k
+
+
 def test_batch_equals_single_calls():
     """a batch of N frames == N independent calls (bit-exact on the same device path)."""
     from densepose_torchscript_amd.predictor import DensePosePredictor

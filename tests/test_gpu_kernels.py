@@ -370,10 +370,15 @@ def _random_boxes(rng, n, size=400.0, zero_frac=0.05):
     return b
 
 
+@pytest.mark.parametrize("reference", ["cpu", "cuda"])
 @pytest.mark.parametrize("n_slots,groups", [(1000, 1), (900, 5), (5000, 5), (37, 2), (1, 1), (63, 1), (64, 2), (65, 3), (129, 1), (4097, 5)])
-def test_batched_nms_matches_oracle(eng, n_slots, groups):
+def test_batched_nms_matches_oracle(eng, n_slots, groups, reference, monkeypatch):
+    """Both strategy switches of torchvision's batched_nms: 4000 box elements (the reference on the CPU) and 20000 (its CUDA mode,
+    run.py:22-29); n_slots = 4097 / 5000 with ~90 % valid boxes sit between the two, so the two modes take different strategies there."""
     from oracle import ops_ref
+    from densepose_torchscript_amd.engine import NMS_TRICK_MAX_NUMEL
     e = eng["fp32"]
+    monkeypatch.setattr(e, "nms_reference", reference)
     rng = np.random.default_rng(n_slots)
     n_img = 2
     boxes = np.stack([_random_boxes(rng, n_slots) for _ in range(n_img)])
@@ -387,7 +392,8 @@ def test_batched_nms_matches_oracle(eng, n_slots, groups):
     for i in range(n_img):
         v = valid[i].astype(bool)
         idx = np.nonzero(v)[0]
-        keep = ops_ref.batched_nms(torch.from_numpy(boxes[i][v]), torch.from_numpy(scores[i][v]), torch.from_numpy(group[i][v]).long(), 0.7)
+        keep = ops_ref.batched_nms(torch.from_numpy(boxes[i][v]), torch.from_numpy(scores[i][v]), torch.from_numpy(group[i][v]).long(), 0.7,
+                                   trick_max_numel=NMS_TRICK_MAX_NUMEL[reference])
         keep = idx[keep.numpy()][:300]
         cnt = int(oc[i])
         assert cnt == len(keep)

@@ -28,6 +28,11 @@ for it in range(steps):
                 if not torch.equal(a[k], b[k].to(a[k].device)):
                     bad += 1
 pred.join(); torch.cuda.synchronize()
+for s0, out in window:               # the last two batches, still in the window when the loop ends
+    for a, b in zip(ref[s0], out):
+        for k in a:
+            if not torch.equal(a[k], b[k].to(a[k].device)):
+                bad += 1
 dt = time.perf_counter() - t0
 print("soak: %d batches, %d mismatching tensors, %.1f img/s (with the comparisons in the loop)" % (steps, bad, steps * 8 / dt))
 sys.exit(1 if bad else 0)
