@@ -47,10 +47,10 @@ struct ConvArgs {
   const float* bias;
   const void* residual;
   void* out;
-  int N, H, W, Cin, Ho, Wo, Cout, Kpad, stride, hi_off, wi_off, relu, rshift, out_f32;
+  int N, H, W, Cin, Ho, Wo, Cout, Kpad, stride, stride_w, hi_off, wi_off, relu, rshift, out_f32;
   long long osN, osH, osW, rsN, rsH, rsW;
   int M, tiles_n, n_ktiles, HoWo, n_tiles;
-  unsigned in_bytes, w_bytes;   // buffer-resource extents (ring kernels)
+  unsigned in_bytes, w_bytes, res_bytes;   // buffer-resource extents (ring / streaming kernels)
   int ntaps, out_linear, res_linear;
 };
 
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs 
       const int ho = rem / p.Wo;
       const int wo = rem - ho * p.Wo;
       a_hi0[i] = ho * p.stride + p.hi_off;
-      a_wi0[i] = wo * p.stride + p.wi_off;
+      a_wi0[i] = wo * p.stride_w + p.wi_off;
       a_pix[i] = n * p.H * p.W;
     } else {
       a_hi0[i] = -(1 << 28);
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
       const int rem = m - n * p.HoWo;
       const int ho = rem / p.Wo;
       const int wo = rem - ho * p.Wo;
-      const int hi0 = ho * p.stride + p.hi_off, wi0 = wo * p.stride + p.wi_off;
+      const int hi0 = ho * p.stride + p.hi_off, wi0 = wo * p.stride_w + p.wi_off;
       a_boff[i] = (((n * p.H + hi0) * p.W + wi0) * p.Cin + scc * CH) * ES;
       for (int t = 0; t < p.ntaps; ++t) {
         const i32x4 e = ktab_c[t * 4];  // planes 0..ntaps-1 enumerate the taps (channel-block-major packing)
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(512, 4) void conv_ring2_kernel(const ConvArgs p) {
       const int rem = m - n * p.HoWo;
       const int ho = rem / p.Wo;
       const int wo = rem - ho * p.Wo;
-      const int hi0 = ho * p.stride + p.hi_off, wi0 = wo * p.stride + p.wi_off;
+      const int hi0 = ho * p.stride + p.hi_off, wi0 = wo * p.stride_w + p.wi_off;
       a_boff[i] = (((n * p.H + hi0) * p.W + wi0) * p.Cin + scc * CH) * ES;
       for (int t = 0; t < p.ntaps; ++t) {
         const i32x4 e = ktab_c[t * 4];
@@ -737,10 +737,22 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const ConvArgs p
   // clamping or predication, 32-bit offsets with the plane / run displacement in the instruction's immediate.
   const bool has_res = p.residual != nullptr;
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(has_res ? p.residual : p.in), 0, has_res ? (unsigned)((long long)p.M * p.rsW * 2) : 0u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)((long long)p.M * p.osW * 2), 0x00020000);
   const int in_pitch = p.Cin * 2, res_pitch = (int)p.rsW * 2, out_pitch = (int)p.osW * 2;
+  // residual: plain NHWC of the output's shape (rshift = 0, res_linear) or the top-down map of the FPN, read through a nearest
+  // x2 up-sampling (fpn.py:152: element (n, ho >> 1, wo >> 1)); res_bytes covers exactly its N images, so rows >= M are dropped
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(has_res ? p.residual : p.in), 0, has_res ? p.res_bytes : 0u, 0x00020000);
+  const bool res_up = has_res && !p.res_linear;
+  auto res_row_off = [&](int m) __attribute__((always_inline)) -> int {   // byte offset of pixel m's residual row
+    if (!res_up) return m * res_pitch;
+    if (m >= p.M) return 0x7ffffff0;   // past the end: out of range whatever the image count
+    const int n = m / p.HoWo;
+    const int rem = m - n * p.HoWo;
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    return (int)(n * p.rsN + (ho >> p.rshift) * p.rsH + (wo >> p.rshift) * p.rsW) * 2;
+  };
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)((long long)p.M * p.osW * 2), 0x00020000);
   const int col_b = (n0 + fq * 8) * 2;   // byte offset of this lane's first run inside a pixel's channel row
 
   u32x4 a[KP][TP];        // pixel fragments (MFMA B operand): pixel fr of tile j, K chunk fq of plane kp
@@ -751,8 +763,9 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const ConvArgs p
 #pragma unroll
     for (int kp = 0; kp < KP; ++kp) a[kp][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, m * in_pitch + fq * 16 + kp * 64, 0, 0);
     if (has_res) {
+      const int ro = res_row_off(m);
 #pragma unroll
-      for (int q = 0; q < NB * 2; ++q) r[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, m * res_pitch + col_b + q * 64, 0, 0);
+      for (int q = 0; q < NB * 2; ++q) r[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro + col_b + q * 64, 0, 0);
     }
   }
 
@@ -792,7 +805,7 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const ConvArgs p
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
       const int o_off = m_cur[j] * out_pitch + col_b;
-      const int r_off = m_nxt[j] * res_pitch + col_b;
+      const int r_off = (has_res ? res_row_off(m_nxt[j]) : 0) + col_b;
 #pragma unroll
       for (int q = 0; q < NB * 2; ++q) {
         const int b = q >> 1, h = q & 1;
@@ -878,9 +891,12 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   const int kb = p->Cin * es;
   const bool lin_out = p->osH == (long long)p->Wo * p->osW && p->osN == (long long)p->Ho * p->osH;
   const bool lin_res = !p->residual || (p->rshift == 0 && p->rsH == (long long)p->Wo * p->rsW && p->rsN == (long long)p->Ho * p->rsH);
-  const bool stream_ok = es == 2 && p->ntaps == 1 && p->stride == 1 && p->hi_off == 0 && p->wi_off == 0 && p->H == p->Ho && p->W == p->Wo &&
+  // ... or the FPN top-down map read through a nearest x2 up-sampling (rshift 1, a plain NHWC tensor of half the size)
+  const bool up_res = p->residual && p->rshift == 1 && p->Ho % 2 == 0 && p->Wo % 2 == 0 && p->rsH == (long long)(p->Wo / 2) * p->rsW &&
+                      p->rsN == (long long)(p->Ho / 2) * p->rsH && (long long)(p->N + 2) * p->rsN * 2 < (1ll << 31);
+  const bool stream_ok = es == 2 && p->ntaps == 1 && p->stride == 1 && (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == 0 && p->wi_off == 0 && p->H == p->Ho && p->W == p->Wo &&
                          (kb == 128 || kb == 256 || kb == 512) && p->Kpad == p->Cin && p->Cout % 256 == 0 && p->Cout_w % 256 == 0 &&
-                         !p->out_f32 && lin_out && lin_res && M >= 4096 &&
+                         !p->out_f32 && lin_out && (lin_res || up_res) && M >= 4096 &&
                          // 32-bit buffer offsets, rows up to one grid stride of tiles past the end are addressed
                          (M + (1ll << 16)) * 2 * (p->Cin > p->osW ? p->Cin : (p->osW > p->rsW ? p->osW : p->rsW)) < (1ll << 31);
   const char* fe = getenv("DP_CONV_BIG");  // test/debug knob - 0: generic only, 1: 256x256 ring whenever legal, 2: 128x128 ring whenever legal, 5: streaming 1x1 whenever legal
@@ -999,17 +1015,18 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   DP_REQUIRE(p->Cout > 0 && p->Cout % 8 == 0 && p->Cout <= p->Cout_w, "dp_conv2d_nhwc: Cout=%d Cout_w=%d", p->Cout, p->Cout_w);
   DP_REQUIRE(p->Cout_w % 128 == 0, "dp_conv2d_nhwc: Cout_w=%d must be a multiple of 128", p->Cout_w);
   DP_REQUIRE(p->Kpad > 0 && (p->Kpad * es) % kKB == 0, "dp_conv2d_nhwc: Kpad=%d not a multiple of %d bytes", p->Kpad, kKB);
-  DP_REQUIRE(p->stride >= 1, "dp_conv2d_nhwc: stride");
+  DP_REQUIRE(p->stride >= 1 && p->stride_w >= 0, "dp_conv2d_nhwc: stride");
   DP_REQUIRE(M < (1ll << 31) && (long long)p->N * p->H * p->W * p->Cin < (1ll << 31), "dp_conv2d_nhwc: tensor too large for 32-bit pixel index");
   ConvArgs a;
   a.in = p->in; a.weight = p->weight; a.ktab = reinterpret_cast<const i32x4*>(p->ktab); a.bias = p->bias;
   a.residual = p->residual; a.out = p->out;
   a.N = p->N; a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.Ho = p->Ho; a.Wo = p->Wo; a.Cout = p->Cout; a.Kpad = p->Kpad;
-  a.stride = p->stride; a.hi_off = p->hi_off; a.wi_off = p->wi_off; a.relu = p->relu; a.rshift = p->rshift; a.out_f32 = p->out_f32;
+  a.stride = p->stride; a.stride_w = p->stride_w > 0 ? p->stride_w : p->stride; a.hi_off = p->hi_off; a.wi_off = p->wi_off; a.relu = p->relu; a.rshift = p->rshift; a.out_f32 = p->out_f32;
   a.osN = p->osN; a.osH = p->osH; a.osW = p->osW; a.rsN = p->rsN; a.rsH = p->rsH; a.rsW = p->rsW;
   a.M = (int)M; a.HoWo = p->Ho * p->Wo; a.n_ktiles = p->Kpad * es / kKB;
   a.in_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cin * es);
   a.w_bytes = (unsigned)((long long)p->Cout_w * p->Kpad * es);
+  a.res_bytes = p->residual ? (unsigned)((long long)p->N * p->rsN * es) : 0u;
   a.ntaps = p->ntaps;
   a.out_linear = (p->osH == (long long)p->Wo * p->osW && p->osN == (long long)p->Ho * p->osH) ? 1 : 0;
   a.res_linear = (p->residual && p->rshift == 0 && p->rsH == (long long)p->Wo * p->rsW && p->rsN == (long long)p->Ho * p->rsH) ? 1 : 0;

@@ -42,6 +42,34 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ src, T* __restrict
   }
 }
 
+// paired layout (dp_preprocess_params.paired): cell j of a row holds the 4-channel pixels 2j - 3 and 2j - 2
+template <typename T>
+__global__ void preprocess_paired_kernel(const uint8_t* __restrict__ src, T* __restrict__ dst, int n_img, int h, int w, int Hp,
+                                         int Wq, float m0, float m1, float m2, float s0, float s1, float s2) {
+  const long long total = (long long)n_img * Hp * Wq;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % Wq);
+    const long long t = i / Wq;
+    const int y = (int)(t % Hp);
+    const int n = (int)(t / Hp);
+    float4 px[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int x = 2 * j + e - 3;
+      px[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (y < h && x >= 0 && x < w) {
+        const uint8_t* s = src + ((long long)n * 3 * h + y) * w + x;
+        px[e].x = ((float)s[0] - m0) / s0;
+        px[e].y = ((float)s[(long long)h * w] - m1) / s1;
+        px[e].z = ((float)s[2ll * h * w] - m2) / s2;
+      }
+    }
+    T* d = dst + i * 8;
+    store4(d, px[0]);
+    store4(d + 4, px[1]);
+  }
+}
+
 // ---- 3x3 stride-2 pad-1 max pool -------------------------------------------------------------------
 // one workgroup per output row: 32-bit index math, 16-byte (8-channel) accesses
 template <typename T>
@@ -360,8 +388,17 @@ __global__ void broadcast_hw_kernel(const T* __restrict__ in, T* __restrict__ ou
 extern "C" int dp_preprocess_u8(const dp_preprocess_params* p, dp_stream_t stream) {
   DP_REQUIRE(p && p->src && p->dst, "dp_preprocess_u8: null pointer");
   DP_REQUIRE(p->n_img > 0 && p->h > 0 && p->w > 0 && p->Hp >= p->h && p->Wp >= p->w, "dp_preprocess_u8: bad shape");
-  const long long total = (long long)p->n_img * p->Hp * p->Wp;
   hipStream_t s = as_stream(stream);
+  if (p->paired) {
+    DP_REQUIRE(p->Wp % 2 == 0, "dp_preprocess_u8: the paired layout needs an even padded width");
+    const int Wq = p->Wp / 2 + 3;
+    const long long cells = (long long)p->n_img * p->Hp * Wq;
+    DISPATCH_DTYPE(p->dtype,
+                   hipLaunchKernelGGL(preprocess_paired_kernel<T>, dim3(grid_for(cells)), dim3(kBlock), 0, s, p->src, (T*)p->dst,
+                                      p->n_img, p->h, p->w, p->Hp, Wq, p->mean[0], p->mean[1], p->mean[2], p->std[0], p->std[1], p->std[2]));
+    return dp_check_launch("preprocess_paired_kernel");
+  }
+  const long long total = (long long)p->n_img * p->Hp * p->Wp;
   DISPATCH_DTYPE(p->dtype,
                  hipLaunchKernelGGL(preprocess_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, p->src, (T*)p->dst,
                                     p->n_img, p->h, p->w, p->Hp, p->Wp, p->mean[0], p->mean[1], p->mean[2], p->std[0], p->std[1], p->std[2]));

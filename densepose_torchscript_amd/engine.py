@@ -96,8 +96,9 @@ class Engine:
         return torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
 
     def conv(self, layer, x, relu=False, residual=None, rshift=0, out_f32=False, out=None, out_c_stride=None, out_c_off=0,
-             out_geom=None):
-        """x: Act. Returns Act. out_geom: (Ho, Wo, osN, osH, osW, base_elems) override for the sub-pixel deconv."""
+             out_geom=None, out_hw=None):
+        """x: Act. Returns Act. out_geom: (osN, osH, osW, base_elems) override for the sub-pixel deconv; out_hw: (Ho, Wo)
+        override (the paired-pixel stem, whose input is narrower than its output is wide)."""
         p = L.ConvParams()
         N, H, W = x.N, x.H, x.W
         assert x.C == layer.cin, (layer.name, x.C, layer.cin)
@@ -107,6 +108,8 @@ class Engine:
         else:
             # every strided conv of this model has pad = (k-1)/2 -> Ho = floor((H - 1) / s) + 1
             Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        if out_hw is not None:
+            Ho, Wo = out_hw
         cs = out_c_stride or layer.cout
         odt = torch.float32 if out_f32 else self.tdt
         if out is None:
@@ -125,6 +128,7 @@ class Engine:
         p.Ho, p.Wo, p.Cout = Ho, Wo, layer.cout
         p.Cout_w, p.Kpad = layer.cout_w, layer.kpad
         p.stride = s
+        p.stride_w = layer.stride_w
         p.ntaps = layer.ntaps
         if residual is not None:
             p.rsN, p.rsH, p.rsW = residual.H * residual.W * residual.C, residual.W * residual.C, residual.C
@@ -201,23 +205,27 @@ class Engine:
 
     # ------------------------------------------------------------------ stages
     def preprocess(self, images_u8, Hp, Wp):
+        """-> the normalised, zero-padded image in the PAIRED layout the stem consumes ([n, Hp, Wp / 2 + 3, 8]: two 4-channel
+        pixels per cell, shifted right by 3 pixels; dp_preprocess_u8 paired=1, pack.stem_paired_conv)."""
         n, _, h, w = images_u8.shape
-        out = self._empty((n, Hp, Wp, 8))
+        Wq = Wp // 2 + 3
+        out = self._empty((n, Hp, Wq, 8))
         p = L.PreprocessParams()
         p.src, p.dst = images_u8.data_ptr(), out.data_ptr()
+        p.paired = 1
         p.n_img, p.h, p.w, p.Hp, p.Wp, p.dtype = n, h, w, Hp, Wp, self.dt
         for i in range(3):
             p.mean[i] = self.cfg.pixel_mean[i]
             p.std[i] = self.cfg.pixel_std[i]
         L.check(self.lib.dp_preprocess_u8(C.byref(p), self._stream()), "dp_preprocess_u8")
-        return Act(out, n, Hp, Wp, 8)
+        return Act(out, n, Hp, Wq, 8)
 
     def backbone(self, x):
         Ls = self.model.layers
         cfg = self.cfg
         bu = "backbone.bottom_up."
         with self._stage("backbone.stem"):
-            x = self.conv(Ls["stem"], x, relu=True)
+            x = self.conv(Ls["stem"], x, relu=True, out_hw=(x.H // 2, x.W - 3))   # paired cells in, Hp/2 x Wp/2 pixels out
             Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
             pooled = self._empty((x.N, Ho, Wo, x.C))
             L.check(self.lib.dp_maxpool3x3s2_nhwc(x.t.data_ptr(), pooled.data_ptr(), x.N, x.H, x.W, x.C, self.dt, self._stream()), "maxpool")

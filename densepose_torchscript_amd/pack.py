@@ -97,6 +97,7 @@ class PackedConv:
             b[:co] = bias
         self.bias = torch.from_numpy(b).to(device)
         self.ntaps = nt
+        self.stride_w = 0           # horizontal stride when it differs from `stride` (paired-pixel stem), 0 = same
         self.stride = stride
         self.hi_off = hi_off
         self.wi_off = wi_off
@@ -132,6 +133,30 @@ def conv_from_oihw(name, w, bias, cin_alloc, stride, pad, dil, dtype, device, in
             cols.append(w[:, :, r, s])
     wmat = np.stack(cols, axis=1).astype(np.float32)  # [co, ntaps, ci]
     return PackedConv(name, wmat, taps, bias, cin_alloc, co, stride, -pad, -pad, dtype, device, plane_major=plane_major)
+
+
+def stem_paired_conv(name, w, bias, dtype, device):
+    """The 7x7 stride-2 pad-3 stem (resnet.py:350-353) over the PAIRED image layout of dp_preprocess_u8 (paired=1): cell j of a
+    row = the 4-channel pixels 2j - 3 and 2j - 2 (3 real channels + 1 zero each). Output column wo reads pixels 2wo - 3 ..
+    2wo + 3 = cells wo .. wo + 3, so the layer is a 7 x 4-tap convolution with stride (2, 1) over 8-channel cells: tap
+    (dy, dxp), element e * 4 + c  <->  kernel position (dy, dx = 2 dxp + e), channel c (dx = 7 and c = 3 carry zero weights).
+    Same K order as the plain form (dy, dx, c ascending), 224 K elements instead of 392."""
+    co, ci, R, S = w.shape
+    assert (R, S) == (7, 7) and ci <= 3
+    taps, cols = [], []
+    for dy in range(7):
+        for dxp in range(4):
+            cell = np.zeros((co, 8), dtype=np.float32)
+            for e in range(2):
+                dx = 2 * dxp + e
+                if dx < 7:
+                    cell[:, e * 4:e * 4 + ci] = w[:, :, dy, dx]
+            taps.append((dy, dxp))
+            cols.append(cell)
+    layer = PackedConv(name, np.stack(cols, axis=1), taps, bias, 8, co, 2, -3, 0, dtype, device)
+    layer.stride_w = 1
+    layer.macs_per_pixel = co * 49 * ci     # algorithmic MACs (the zero weights of the paired form are not work)
+    return layer
 
 
 def linear_as_conv(name, w, bias, cin_alloc, dtype, device):
@@ -177,7 +202,8 @@ class PackedModel:
                                   st[name + ".bias"].astype(np.float32) if bias else None, cin_alloc, stride, pad, dil, dtype, device, in_hw)
 
         A8 = lambda c: round_up(c, 8)  # noqa: E731
-        L["stem"] = bnconv(bu + "stem.conv1", 8, 2, 3)
+        w, shift = _fold_bn(st[bu + "stem.conv1.weight"].astype(np.float32), st, bu + "stem.conv1.norm")
+        L["stem"] = stem_paired_conv(bu + "stem.conv1", w, shift, dtype, device)
         for stage, b, cin, cmid, cout, stride, sc in resnet_blocks(cfg):
             p = "%s%s.%d." % (bu, stage, b)
             if sc:

@@ -52,6 +52,11 @@ typedef struct {
   int32_t n_img, h, w, Hp, Wp;
   int32_t dtype;
   float mean[3], inv_std_unused[3], std[3];
+  int32_t paired;     /* 0: dst = [n_img][Hp][Wp][8] (3 real channels + 5 zeros per pixel).
+                         1: dst = [n_img][Hp][Wq][8], Wq = Wp / 2 + 3: the image as 4-channel pixels (3 real + 1 zero), shifted
+                            right by 3 pixels, TWO pixels per 8-channel cell - cell j holds pixels 2j - 3 and 2j - 2. The 7x7
+                            stride-2 stem (resnet.py:350-353) then is a 7 x 4-tap convolution with stride (2, 1) over cells:
+                            K = 7 * 4 * 8 = 224 instead of 49 * 8 = 392 (3 of 8 channels used -> 6 of 8). */
 } dp_preprocess_params;
 int dp_preprocess_u8(const dp_preprocess_params* p, dp_stream_t stream);
 
@@ -81,7 +86,8 @@ typedef struct {
   int32_t relu;
   int32_t dtype;         /* dtype of in / weight / residual */
   int32_t out_f32;       /* 1: out is fp32 regardless of dtype */
-  int32_t hi_off, wi_off; /* input pixel of output (ho,wo), tap (dy,dx): (ho*stride + hi_off + dy, wo*stride + wi_off + dx) */
+  int32_t hi_off, wi_off; /* input pixel of output (ho,wo), tap (dy,dx): (ho*stride + hi_off + dy, wo*stride_w + wi_off + dx) */
+  int32_t stride_w;       /* horizontal stride; 0 = same as `stride` (only the paired-pixel stem uses stride 2 x 1) */
 } dp_conv_params;
 int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
 /* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile,

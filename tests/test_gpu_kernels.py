@@ -115,6 +115,43 @@ STREAM_CASES = [
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 256, 48, 64, 256), (3, 64, 40, 38, 256), (1, 128, 70, 62, 512)])
+def test_conv2d_stream_kernel_upsampled_residual(eng, dt, shape, monkeypatch):
+    """FPN lateral + top-down add (fpn.py:150-155: lateral 1x1 conv + F.interpolate(top, x2, nearest)) on the streaming 1x1
+    kernel: the residual is the half-size map read at (ho >> 1, wo >> 1). Same result as the generic kernel bit for bit."""
+    from densepose_torchscript_amd import lib as L
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    e = eng[dt]
+    N, Cin, H, W, Cout = shape
+    g = torch.Generator().manual_seed(Cin + H)
+    x = _round(torch.randn((N, Cin, H, W), generator=g), dt)
+    top = _round(torch.randn((N, Cout, H // 2, W // 2), generator=g), dt)
+    w = _round(torch.randn((Cout, Cin, 1, 1), generator=g) * (1.0 / Cin) ** 0.5, dt)
+    b = torch.randn((Cout,), generator=g)
+    layer = conv_from_oihw("lat", w.numpy(), b.numpy(), Cin, 1, 0, 1, e.dt, e.device)
+    xa = Act(_nhwc(x, Cin, e.tdt, e.device), N, H, W, Cin)
+    ta = Act(_nhwc(top, Cout, e.tdt, e.device), N, H // 2, W // 2, Cout)
+    monkeypatch.setenv("DP_CONV_STREAM", "0")
+    want = e.conv(layer, xa, residual=ta, rshift=1)
+    monkeypatch.delenv("DP_CONV_STREAM")
+    p = L.ConvParams()
+    p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, Cin, H, W, Cout, Cout, Cin
+    p.stride, p.ntaps, p.dtype, p.out_f32, p.rshift = 1, 1, e.dt, 0, 1
+    p.osN, p.osH, p.osW = H * W * Cout, W * Cout, Cout
+    p.rsN, p.rsH, p.rsW = (H // 2) * (W // 2) * Cout, (W // 2) * Cout, Cout
+    p.residual = ta.t.data_ptr()
+    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 5      # this launch really is the streaming kernel
+    got = e.conv(layer, xa, residual=ta, rshift=1)
+    torch.cuda.synchronize()
+    assert torch.equal(got.t, want.t)
+    ref = F.conv2d(x.double(), w.double(), b.double()) + F.interpolate(top.double(), scale_factor=2.0, mode="nearest")
+    ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    gd = got.t.float().cpu().permute(0, 3, 1, 2).double()
+    assert bool(((gd - ref).abs() <= ulp * ref.abs() + 1e-3).all())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", STREAM_CASES)
 def test_conv2d_stream_kernel(eng, dt, case, monkeypatch):
     from densepose_torchscript_amd import lib as L
@@ -262,6 +299,54 @@ def test_bottleneck_tail_unsupported_shapes_fall_back(eng):
     p = __import__("densepose_torchscript_amd.lib", fromlist=["x"]).BottleneckParams()
     p.N, p.H, p.W, p.Cmid, p.Cout, p.Kpad2, p.Kpad3, p.ntaps2, p.dtype = 1, 8, 8, 32, 128, 288, 64, 9, eb.dt
     assert eb.lib.dp_bottleneck_tail_nhwc(C.byref(p), eb._stream()) == -2   # DP_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 61, 90, 64, 96), (1, 64, 96, 64, 96), (3, 33, 37, 64, 64), (1, 32, 32, 32, 32)])
+def test_paired_preprocess_and_stem(eng, dt, shape):
+    """preprocess_image (rcnn.py:156-181: (x - mean) / std, zero pad to /32) written in the paired-pixel layout + the stem
+    (resnet.py:350-353: 7x7 stride 2 pad 3 + FrozenBN + ReLU) as a 7 x 4-tap stride-(2,1) convolution over 8-channel cells,
+    against F.conv2d on the plainly normalised, padded image."""
+    from densepose_torchscript_amd import lib as L
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import stem_paired_conv
+    e = eng[dt]
+    n, h, w, Hp, Wp = shape
+    g = torch.Generator().manual_seed(n * 100 + h + w)
+    img = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8)
+    mean, std = (103.53, 116.28, 123.675), (1.0, 57.375, 58.395)
+    x = (img.float() - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    xp = torch.zeros((n, 3, Hp, Wp))
+    xp[:, :, :h, :w] = x
+    # the paired buffer itself: cell j = pixels 2j - 3, 2j - 2 (4 channels each, the 4th zero)
+    Wq = Wp // 2 + 3
+    buf = torch.full((n, Hp, Wq, 8), 7.0, dtype=e.tdt, device=e.device)
+    p = L.PreprocessParams()
+    src = img.to(e.device)
+    p.src, p.dst, p.paired = src.data_ptr(), buf.data_ptr(), 1
+    p.n_img, p.h, p.w, p.Hp, p.Wp, p.dtype = n, h, w, Hp, Wp, e.dt
+    for i in range(3):
+        p.mean[i], p.std[i] = mean[i], std[i]
+    L.check(e.lib.dp_preprocess_u8(C.byref(p), e._stream()), "dp_preprocess_u8")
+    cells = buf.float().cpu().view(n, Hp, 2 * Wq, 4)
+    want = torch.zeros((n, Hp, 2 * Wq, 4))
+    want[:, :, 3:3 + Wp, :3] = xp.permute(0, 2, 3, 1)
+    ulp = {"fp32": 0.0, "bf16": 2.0 ** -8, "fp16": 2.0 ** -11}[dt]
+    assert bool(((cells - want).abs() <= ulp * want.abs() + 1e-6).all())
+    # stem on it
+    wt = torch.randn((16, 3, 7, 7), generator=g) * 0.05
+    b = torch.randn((16,), generator=g)
+    if dt != "fp32":
+        wt = _round(wt, dt)
+    layer = stem_paired_conv("stem", wt.numpy(), b.numpy(), e.dt, e.device)
+    out = e.conv(layer, Act(buf, n, Hp, Wq, 8), relu=True, out_hw=(Hp // 2, Wp // 2), out_f32=True)
+    torch.cuda.synchronize()
+    xin = want[:, :, 3:3 + Wp, :3].permute(0, 3, 1, 2) if dt == "fp32" else cells[:, :, 3:3 + Wp, :3].permute(0, 3, 1, 2)
+    ref = F.relu(F.conv2d(xin.double(), wt.double(), b.double(), stride=2, padding=3))
+    got = out.t.cpu()[..., :16].permute(0, 3, 1, 2).double()
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())) * (147 ** 0.5)
+    assert layer.kpad == (224 if dt == "fp32" else 256) and layer.macs_per_pixel == 16 * 147   # 7 x 4 taps x 8, padded to 128 B
 
 
 def test_conv_fpn_lateral_plus_nearest_upsample(eng):
