@@ -171,19 +171,6 @@ __global__ __launch_bounds__(kBlock) void upsample2x_kernel(const T* __restrict_
   }
 }
 
-template <typename T>
-__global__ void add_kernel(const T* __restrict__ in, T* __restrict__ out, long long count4) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += (long long)gridDim.x * blockDim.x) {
-    const float4 a = load4(in + i * 4), o = load4(out + i * 4);
-    store4(out + i * 4, make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w));
-  }
-}
-
-template <typename TI, typename TO>
-__global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long long count) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
-    Elem<TO>::store(out + i, Elem<TI>::load(in + i));
-}
 
 // ---- K18: bilinear x2 + channel split + NHWC -> NCHW (fp32) --------------------------------------------
 // One workgroup per (roi, source row pair i, i+1): the two low-res rows are brought into LDS with coalesced
@@ -435,37 +422,6 @@ extern "C" int dp_upsample_bilinear2x_nhwc(const void* in, void* out, int N, int
   return dp_check_launch("upsample2x_kernel");
 }
 
-extern "C" int dp_add_nhwc(const void* in, void* out, int64_t count, int dtype, dp_stream_t stream) {
-  DP_REQUIRE(in && out && count >= 0 && count % 4 == 0, "dp_add_nhwc: bad args");
-  if (count == 0) return DP_OK;
-  hipStream_t s = as_stream(stream);
-  DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(add_kernel<T>, dim3(grid_for(count / 4)), dim3(kBlock), 0, s, (const T*)in, (T*)out, (long long)count / 4));
-  return dp_check_launch("add_kernel");
-}
-
-extern "C" int dp_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t count, dp_stream_t stream) {
-  DP_REQUIRE(in && out && count >= 0, "dp_cast: bad args");
-  if (count == 0) return DP_OK;
-  hipStream_t s = as_stream(stream);
-  const dim3 g(grid_for(count)), b(kBlock);
-#define DP_CAST_CASE(DI, TI, DO, TO)                                                                                     \
-  if (in_dtype == DI && out_dtype == DO)                                                                                 \
-    hipLaunchKernelGGL((cast_kernel<TI, TO>), g, b, 0, s, (const TI*)in, (TO*)out, (long long)count);                    \
-  else
-  DP_CAST_CASE(DP_F32, float, DP_F32, float)
-  DP_CAST_CASE(DP_F32, float, DP_BF16, uint16_t)
-  DP_CAST_CASE(DP_F32, float, DP_F16, f16_t)
-  DP_CAST_CASE(DP_BF16, uint16_t, DP_F32, float)
-  DP_CAST_CASE(DP_BF16, uint16_t, DP_BF16, uint16_t)
-  DP_CAST_CASE(DP_BF16, uint16_t, DP_F16, f16_t)
-  DP_CAST_CASE(DP_F16, f16_t, DP_F32, float)
-  DP_CAST_CASE(DP_F16, f16_t, DP_BF16, uint16_t)
-  DP_CAST_CASE(DP_F16, f16_t, DP_F16, f16_t)
-    return dp_fail(DP_ERR_BAD_ARG, "dp_cast: bad dtypes %d -> %d", in_dtype, out_dtype);
-#undef DP_CAST_CASE
-  return dp_check_launch("cast_kernel");
-}
 
 extern "C" int dp_iuv_upsample_split(const dp_iuv_params* p, dp_stream_t stream) {
   DP_REQUIRE(p, "dp_iuv_upsample_split: null params");

@@ -108,6 +108,14 @@ class IuvExtractParams(C.Structure):
                 ("box_xywh", c_void_p), ("out_offset", c_void_p), ("labels", c_void_p), ("uv", c_void_p), ("max_hw", c_i32)]
 
 
+class PackParams(C.Structure):
+    _fields_ = [("Cout", c_i32), ("ntaps", c_i32), ("Cin", c_i32), ("cin_alloc", c_i32), ("dtype", c_i32), ("tap_major", c_i32)]
+
+
+class PackInfo(C.Structure):
+    _fields_ = [("cout", c_i32), ("cout_w", c_i32), ("kpad", c_i32), ("n_ktab", c_i32), ("plane_major", c_i32)]
+
+
 # every symbol include/densepose_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "dp_abi_version": (c_int, []),
@@ -121,7 +129,6 @@ SYMBOLS = {
     "dp_maxpool3x3s2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_subsample2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_upsample_bilinear2x_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dp_add_nhwc": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "dp_merge_upsample2x_nhwc": (c_int, [c_void_p, C.POINTER(c_void_p), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_rpn_topk_workspace_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
     "dp_rpn_topk_decode": (c_int, [C.POINTER(RpnLevelParams), c_void_p]),
@@ -135,7 +142,10 @@ SYMBOLS = {
     "dp_groupnorm_relu_nhwc": (c_int, [C.POINTER(GroupNormParams), c_void_p]),
     "dp_global_avgpool_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_broadcast_hw_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dp_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_i64, c_void_p]),
+    "dp_fold_frozen_bn": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "dp_conv_taps": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dp_pack_conv_info": (c_int, [C.POINTER(PackParams), C.POINTER(PackInfo)]),
+    "dp_pack_conv_weights": (c_int, [C.POINTER(PackParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dp_resize_u8_bilinear": (c_int, [C.POINTER(ResizeParams), c_void_p]),
     "dp_resize_u8_bilinear_batch": (c_int, [C.POINTER(ResizeParams), C.POINTER(c_void_p), c_int, c_void_p]),
     "dp_iuv_extract": (c_int, [C.POINTER(IuvExtractParams), c_void_p]),
@@ -146,17 +156,40 @@ class DensePoseHipError(RuntimeError):
     pass
 
 
+def _source_digest():
+    """sha256 over every source the library is built from (kernels, headers, Makefile), in a fixed order."""
+    import hashlib
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile"]
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "densepose_hip.h"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def build_library(force=False):
-    """hipcc --offload-arch=gfx950 -shared (cross-compiles without a GPU). Built IN-TREE so it travels."""
-    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
-    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "densepose_hip.h"))
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+    """hipcc --offload-arch=gfx950 -shared (cross-compiles without a GPU). Built IN-TREE so it travels.
+    Up to date = the digest of the sources equals the one recorded beside the .so when it was built (file times mean
+    nothing on a fresh checkout or after the tree was copied to the GPU box)."""
+    stamp = LIB_PATH + ".sha256"
+    digest = _source_digest()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
         return LIB_PATH
     subprocess.check_call(["make", "-C", CSRC, "-B"])
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
     return LIB_PATH
 
 
 _lib = None
+
+
+if __name__ == "__main__":   # `python lib.py stamp`: record the source digest beside a library built by hand (make)
+    import sys
+    if sys.argv[1:] == ["stamp"]:
+        with open(LIB_PATH + ".sha256", "w") as f:
+            f.write(_source_digest() + "\n")
 
 
 def load():

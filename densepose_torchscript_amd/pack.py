@@ -3,13 +3,18 @@
 * FrozenBN folded into the conv (scale into the weights, shift into the bias):
   y = (x - mean) * rsqrt(var + 1e-5) * gamma + beta   (/root/reference/detectron2/layers/batch_norm.py:31,54-62)
 * OIHW -> [Cout_pad128][K] with K = (tap, channel) contiguous ("KRSC"), zero padded to the 128-byte K step,
-  plus the per-16-byte-chunk tap table (ktab) consumed by dp_conv2d_nhwc.
+  plus the per-16-byte-chunk tap table (ktab) consumed by dp_conv2d_nhwc. Both steps (and the BN fold) are host-side entry
+  points of the C ABI (dp_fold_frozen_bn, dp_conv_taps, dp_pack_conv_weights: csrc/dp_pack.cpp); this module decides WHAT to
+  pack (layer list, fc1 / deconv / stem re-arrangements) and uploads the result.
 * fc1's K axis is permuted from the reference's NCHW flatten (c, y, x) (box_head.py:70-71) to NHWC (y, x, c).
 * ConvTranspose2d(k4, s2, p1) (chart.py:45-59) is split into its four 2x2 sub-pixel convolutions.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
+from . import lib as L
 from .lib import DP_BF16, DP_F16, DP_F32
 from .weights import decoder_layout, resnet_blocks
 
@@ -20,82 +25,46 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def _cout_row_perm():
-    """Row order of the weight matrix inside every 64-cout block (dp_conv.hip store_tile): physical row i*16 + q*4 + e - row
-    q*4+e of the i-th 16x16 MFMA tile a wave owns along cout - carries logical cout (i>>1)*32 + q*8 + (i&1)*4 + e, so that the
-    accumulator registers of one lane are two runs of 8 consecutive output channels (16-byte stores straight from registers)."""
-    perm = np.zeros(64, dtype=np.int64)
-    for i in range(4):
-        for q in range(4):
-            for e in range(4):
-                perm[i * 16 + q * 4 + e] = (i >> 1) * 32 + q * 8 + (i & 1) * 4 + e
-    return perm
-
-
-COUT_ROW_PERM = _cout_row_perm()
-
-
 class PackedConv:
-    """One dp_conv2d_nhwc layer resident on the device."""
+    """One dp_conv2d_nhwc layer resident on the device. The packing itself (row permutation, K order, tap table, dtype
+    conversion) is the C ABI's host-side packer (dp_pack_conv_weights, csrc/dp_pack.cpp); tests/test_pack.py checks it
+    against an independent numpy restatement."""
 
     def __init__(self, name, wmat, taps, bias, cin_alloc, cout, stride, hi_off, wi_off, dtype, device, plane_major=None):
         # wmat: float32 [Cout, ntaps, Cin] ; taps: list of (dy, dx)
-        self.name = name
-        self.dtype = dtype
-        es = 4 if dtype == DP_F32 else 2
-        ch = 16 // es
-        co, nt, ci = wmat.shape
-        assert nt == len(taps) and ci <= cin_alloc and cin_alloc % 8 == 0
-        self.cin = cin_alloc
-        self.cout = round_up(cout, 8)
-        self.cout_w = round_up(cout, 128)
-        k = nt * cin_alloc
-        self.kpad = round_up(k, 128 // es)
-        full = np.zeros((self.cout_w, nt, cin_alloc), dtype=np.float32)
-        full[:co, :, :ci] = wmat
-        pe = 64 // es  # elements of one 64-byte K plane
-        # K order. Multi-tap layers whose channel count is a whole number of planes are packed CHANNEL-BLOCK major,
-        # taps inner: consecutive K planes then read the same pixels shifted by one tap, so the 3 dx taps (and, through
-        # the neighbouring tiles that run at the same time on the same XCD, the 3 dy taps) of an activation hit in L2
-        # instead of being re-fetched from beyond it 9 times (tap-major order sweeps the whole input once per tap).
         # plane_major=False (opt-in, PackedModel uses it for the res2 conv2 layers) keeps K TAP major - K = tap * Cin +
         # channel - which is what the fused bottleneck tail (dp_bottleneck_tail_nhwc) consumes: the two 64-byte halves of a
         # pixel's 128-byte line are then read by consecutive loads. Only for layers that run on the table-driven generic
         # kernel (Cout <= 64): the LDS-ring kernels enumerate the taps as planes 0..ntaps-1 of the channel-block-major order.
-        if plane_major is None:
-            plane_major = True
-        assert plane_major or co <= 64, "tap-major packing is only legal for layers on the generic kernel (Cout <= 64)"
-        self.plane_major = bool(plane_major) and nt > 1 and cin_alloc % pe == 0
-        if self.plane_major:
-            ncb = cin_alloc // pe
-            full = full.reshape(self.cout_w, nt, ncb, pe).transpose(0, 2, 1, 3)  # [co, cblock, tap, pe]
-        flat = np.zeros((self.cout_w, self.kpad), dtype=np.float32)
-        flat[:, :k] = full.reshape(self.cout_w, k)
-        flat = flat[COUT_ROW_PERM[None, :] + 64 * np.arange(self.cout_w // 64)[:, None]].reshape(self.cout_w, self.kpad)
-        t = torch.from_numpy(flat)
+        lib = L.load()
+        self.name = name
+        self.dtype = dtype
+        wmat = np.ascontiguousarray(wmat, dtype=np.float32)
+        co, nt, ci = wmat.shape
+        assert nt == len(taps) and ci <= cin_alloc and cin_alloc % 8 == 0 and co == cout
+        p = L.PackParams()
+        p.Cout, p.ntaps, p.Cin, p.cin_alloc, p.dtype = co, nt, ci, cin_alloc, dtype
+        p.tap_major = 1 if plane_major is False else 0
+        info = L.PackInfo()
+        L.check(lib.dp_pack_conv_info(C.byref(p), C.byref(info)), "dp_pack_conv_info[%s]" % name)
+        self.cin = cin_alloc
+        self.cout, self.cout_w, self.kpad = info.cout, info.cout_w, info.kpad
+        self.plane_major = bool(info.plane_major)
+        wdt = {DP_F32: np.float32, DP_BF16: np.uint16, DP_F16: np.float16}[dtype]
+        w_out = np.empty((self.cout_w, self.kpad), dtype=wdt)
+        ktab = np.empty((info.n_ktab, 4), dtype=np.int32)
+        b_out = np.empty((self.cout_w,), dtype=np.float32)
+        taps_a = np.ascontiguousarray(np.asarray(taps, dtype=np.int32).reshape(nt, 2))
+        bias_a = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32)
+        assert bias_a is None or bias_a.shape == (co,)
+        L.check(lib.dp_pack_conv_weights(C.byref(p), wmat.ctypes.data, taps_a.ctypes.data, None if bias_a is None else bias_a.ctypes.data,
+                                         w_out.ctypes.data, ktab.ctypes.data, b_out.ctypes.data), "dp_pack_conv_weights[%s]" % name)
+        t = torch.from_numpy(w_out)
         if dtype == DP_BF16:
-            t = t.to(torch.bfloat16)
-        elif dtype == DP_F16:
-            t = t.to(torch.float16)  # the reference's .half() (export.py:36-37), applied to the BN-folded weights
+            t = t.view(torch.bfloat16)
         self.weight = t.to(device).contiguous()
-        nchunk = self.kpad // ch
-        ktab = np.zeros((nchunk, 4), dtype=np.int32)
-        for kc in range(nchunk):
-            k0 = kc * ch
-            if k0 >= k:
-                continue
-            if self.plane_major:
-                plane, within = divmod(k0, pe)
-                cb, tap = divmod(plane, nt)
-                c0 = cb * pe + within
-            else:
-                tap, c0 = divmod(k0, cin_alloc)
-            ktab[kc] = (taps[tap][0], taps[tap][1], c0, 1 | (tap << 8))
         self.ktab = torch.from_numpy(ktab).to(device)
-        b = np.zeros((self.cout_w,), dtype=np.float32)
-        if bias is not None:
-            b[:co] = bias
-        self.bias = torch.from_numpy(b).to(device)
+        self.bias = torch.from_numpy(b_out).to(device)
         self.ntaps = nt
         self.stride_w = 0           # horizontal stride when it differs from `stride` (paired-pixel stem), 0 = same
         self.stride = stride
@@ -108,31 +77,29 @@ class PackedConv:
 
 
 def _fold_bn(w, st, norm_name):
-    g = st[norm_name + ".weight"].astype(np.float32)
-    b = st[norm_name + ".bias"].astype(np.float32)
-    m = st[norm_name + ".running_mean"].astype(np.float32)
-    v = st[norm_name + ".running_var"].astype(np.float32)
-    scale = g * (np.float32(1.0) / np.sqrt(v + np.float32(BN_EPS)))
-    shift = b - m * scale
-    return w * scale[:, None, None, None], shift
+    """FrozenBN folded into the conv (batch_norm.py:31,54-62) by dp_fold_frozen_bn: (scaled weights, per-cout shift)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    g, b, m, v = (np.ascontiguousarray(st[norm_name + s], dtype=np.float32) for s in (".weight", ".bias", ".running_mean", ".running_var"))
+    co = w.shape[0]
+    w_out, shift = np.empty_like(w), np.empty((co,), dtype=np.float32)
+    L.check(L.load().dp_fold_frozen_bn(w.ctypes.data, co, w.size // co, g.ctypes.data, b.ctypes.data, m.ctypes.data, v.ctypes.data,
+                                       BN_EPS, w_out.ctypes.data, shift.ctypes.data), "dp_fold_frozen_bn[%s]" % norm_name)
+    return w_out, shift
 
 
 def conv_from_oihw(name, w, bias, cin_alloc, stride, pad, dil, dtype, device, in_hw=None, plane_major=None):
     co, ci, R, S = w.shape
-    taps, cols = [], []
-    for r in range(R):
-        for s in range(S):
-            dy, dx = r * dil, s * dil
-            if in_hw is not None and stride == 1:
-                # a tap that can never land inside the map for ANY output pixel contributes exactly 0
-                # (deeplab.py:33 dilation 56 on a 28x28 ROI map: only the centre tap survives)
-                H, W = in_hw
-                if (dy - pad >= H) or (dy - pad <= -H) or (dx - pad >= W) or (dx - pad <= -W):
-                    continue
-            taps.append((dy, dx))
-            cols.append(w[:, :, r, s])
-    wmat = np.stack(cols, axis=1).astype(np.float32)  # [co, ntaps, ci]
-    return PackedConv(name, wmat, taps, bias, cin_alloc, co, stride, -pad, -pad, dtype, device, plane_major=plane_major)
+    taps = np.empty((R * S, 2), dtype=np.int32)
+    pos = np.empty((R * S,), dtype=np.int32)
+    # taps that can never land inside the map for ANY output pixel contribute exactly 0 and are dropped
+    # (deeplab.py:33 dilation 56 on a 28x28 ROI map: only the centre tap survives)
+    H, W = in_hw if in_hw is not None else (0, 0)
+    nt = L.load().dp_conv_taps(R, S, pad, dil, stride, H, W, taps.ctypes.data, pos.ctypes.data)
+    if nt <= 0:
+        raise L.DensePoseHipError("dp_conv_taps[%s] failed (%d)" % (name, nt))
+    wmat = np.stack([w[:, :, int(q) // S, int(q) % S] for q in pos[:nt]], axis=1).astype(np.float32)  # [co, ntaps, ci]
+    return PackedConv(name, wmat, [tuple(t) for t in taps[:nt].tolist()], bias, cin_alloc, co, stride, -pad, -pad, dtype, device,
+                      plane_major=plane_major)
 
 
 def stem_paired_conv(name, w, bias, dtype, device):

@@ -140,8 +140,6 @@ int dp_upsample_bilinear2x_nhwc(const void* in, void* out, int N, int H, int W, 
  * the decoder's level sum in one pass. ups are [N,H,W,C], base/out [N,2H,2W,C] (out may alias base). */
 int dp_merge_upsample2x_nhwc(const void* base, const void* const* ups, int n_ups, void* out, int N, int H, int W, int C,
                              int dtype, dp_stream_t stream);
-/* elementwise out += in (decoder level sum when no upsample is involved) */
-int dp_add_nhwc(const void* in, void* out, int64_t count, int dtype, dp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K9   proposal_utils.py:76   logits_i.topk(min(HiWiA, k)) per image and level (sorted, desc)
@@ -259,8 +257,39 @@ int dp_global_avgpool_nhwc(const void* in, void* out, int R, int HW, int C, int 
 int dp_broadcast_hw_nhwc(const void* in, void* out, int R, int HW, int C, int out_c_stride, int out_c_off, int dtype,
                          dp_stream_t stream);
 
-/* dtype conversion helper (weights upload, debugging) */
-int dp_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t count, dp_stream_t stream);
+/* ---------------------------------------------------------------------------------------------
+ * Host-side weight pipeline (CPU code, no stream): canonical fp32 parameters -> the packed operands of
+ * dp_conv2d_nhwc / dp_bottleneck_tail_nhwc. What the reference does implicitly by handing nn.Conv2d /
+ * FrozenBatchNorm2d parameters to ATen (wrappers.py:104-112, batch_norm.py:31,54-62).
+ * ------------------------------------------------------------------------------------------- */
+/* FrozenBN fold: w_out[co][..] = w[co][..] * scale[co], shift[co] = beta - mean * scale, scale = gamma * (1 / sqrt(var + eps)),
+ * all in fp32 (per_cout = Cin * R * S elements per output channel; w_out may alias w) */
+int dp_fold_frozen_bn(const float* w, int Cout, int per_cout, const float* gamma, const float* beta, const float* mean,
+                      const float* var, float eps, float* w_out, float* shift_out);
+/* tap list of an R x S kernel: taps_out[n] = {r * dilation, s * dilation}, kernel_pos_out[n] = r * S + s, row-major; with
+ * stride 1 and in_h, in_w > 0 the taps that cannot land inside an in_h x in_w map for any output pixel are dropped
+ * (deeplab.py:33: dilation 56 on a 28x28 map). Returns the number of taps kept (< 0: error); hi_off = wi_off = -pad. */
+int dp_conv_taps(int R, int S, int pad, int dilation, int stride, int in_h, int in_w, int32_t* taps_out, int32_t* kernel_pos_out);
+typedef struct {
+  int32_t Cout, ntaps, Cin;   /* wmat: [Cout][ntaps][Cin] fp32 (tap t of an OIHW kernel = w[:, :, r, s] of dp_conv_taps) */
+  int32_t cin_alloc;          /* channels of the NHWC tensor the layer reads (multiple of 8, >= Cin; extra channels get zero weights) */
+  int32_t dtype;              /* storage type of the packed weights */
+  int32_t tap_major;          /* 0: multi-tap layers whose cin_alloc is whole 64-byte planes are packed channel-block major, taps
+                                 inner (what the LDS-ring kernels expect); 1: K = tap * cin_alloc + channel (generic kernel only:
+                                 Cout <= 64; the order dp_bottleneck_tail_nhwc takes for conv2) */
+} dp_pack_params;
+typedef struct {
+  int32_t cout;      /* channels the layer stores (Cout rounded up to 8) */
+  int32_t cout_w;    /* rows of the packed matrix (Cout rounded up to 128) */
+  int32_t kpad;      /* elements per row (K rounded up to 128 bytes) */
+  int32_t n_ktab;    /* tap table entries (int32[4] each) = kpad / elements per 16-byte chunk */
+  int32_t plane_major; /* 1: channel-block-major K order was used */
+} dp_pack_info;
+int dp_pack_conv_info(const dp_pack_params* p, dp_pack_info* info);
+/* wmat as above, taps [ntaps][2] = {dy, dx}, bias [Cout] or NULL; outputs are HOST buffers sized by dp_pack_conv_info:
+ * w_out [cout_w][kpad] dtype, ktab_out [n_ktab][4], bias_out [cout_w] fp32 */
+int dp_pack_conv_weights(const dp_pack_params* p, const float* wmat, const int32_t* taps, const float* bias, void* w_out,
+                         int32_t* ktab_out, float* bias_out);
 
 /* ---------------------------------------------------------------------------------------------
  * "next" rows

@@ -1,0 +1,57 @@
+"""Driven by tests/test_asan.py inside a process that preloads the AddressSanitizer runtime: loads the ASAN build of the
+library (host side instrumented, csrc/Makefile target `asan`) through plain ctypes - no torch, no GPU - and exercises the
+host code that touches caller memory: argument validation of every params struct, the workspace-size queries and the
+weight packer writing into exactly-sized buffers. Any out-of-bounds access aborts the process with an ASAN report."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from densepose_torchscript_amd import lib as L  # noqa: E402  (ctypes + os only)
+
+lib = L.load()
+assert os.path.basename(L.LIB_PATH).endswith("_asan.so"), L.LIB_PATH
+# argument validation: zeroed / inconsistent structs must be rejected before anything is launched
+for cls, fn in ((L.ConvParams, lib.dp_conv2d_nhwc), (L.NmsParams, lib.dp_batched_nms), (L.RoiAlignParams, lib.dp_roi_align_nhwc),
+                (L.BoxDecodeParams, lib.dp_box_decode_score), (L.PostprocessParams, lib.dp_postprocess_boxes),
+                (L.IuvParams, lib.dp_iuv_upsample_split), (L.GroupNormParams, lib.dp_groupnorm_relu_nhwc),
+                (L.PreprocessParams, lib.dp_preprocess_u8), (L.BottleneckParams, lib.dp_bottleneck_tail_nhwc),
+                (L.ResizeParams, lib.dp_resize_u8_bilinear), (L.RpnLevelParams, lib.dp_rpn_topk_decode)):
+    p = cls()
+    rc = fn(C.byref(p), None)
+    assert rc in (0, -1, -2), (cls.__name__, rc)      # 0: an empty problem (R = 0 detections) is legal and launches nothing
+    assert rc == 0 or lib.dp_last_error()
+p = L.ConvParams()
+p.N, p.H, p.W, p.Ho, p.Wo, p.Cin, p.Cout = 1, 4, 4, 4, 4, 7, 8
+assert lib.dp_conv2d_nhwc(C.byref(p), None) == -1
+assert lib.dp_conv2d_kernel_class(C.byref(p)) >= 0 and lib.dp_conv2d_tile_rows(C.byref(p)) > 0
+assert lib.dp_nms_workspace_bytes(2, 1000) > 0 and lib.dp_rpn_topk_workspace_bytes(8, 200, 336, 3) > 0
+# the packer into exactly-sized buffers, every dtype, shapes with ragged padding
+rng = np.random.default_rng(0)
+for dtype, wdt in ((L.DP_F32, np.float32), (L.DP_BF16, np.uint16), (L.DP_F16, np.uint16)):
+    for co, nt, ci, ca, tm in ((64, 49, 3, 8, 0), (64, 9, 64, 64, 1), (130, 1, 16, 16, 0), (15, 9, 24, 24, 0), (256, 9, 256, 256, 0)):
+        q, info = L.PackParams(), L.PackInfo()
+        q.Cout, q.ntaps, q.Cin, q.cin_alloc, q.dtype, q.tap_major = co, nt, ci, ca, dtype, tm
+        assert lib.dp_pack_conv_info(C.byref(q), C.byref(info)) == 0
+        wmat = rng.standard_normal((co, nt, ci)).astype(np.float32)
+        taps = rng.integers(-3, 4, (nt, 2)).astype(np.int32)
+        bias = rng.standard_normal((co,)).astype(np.float32)
+        w_out = np.empty((info.cout_w, info.kpad), dtype=wdt)
+        ktab = np.empty((info.n_ktab, 4), dtype=np.int32)
+        b_out = np.empty((info.cout_w,), dtype=np.float32)
+        assert lib.dp_pack_conv_weights(C.byref(q), wmat.ctypes.data, taps.ctypes.data, bias.ctypes.data, w_out.ctypes.data,
+                                        ktab.ctypes.data, b_out.ctypes.data) == 0
+        assert lib.dp_pack_conv_weights(C.byref(q), wmat.ctypes.data, taps.ctypes.data, None, w_out.ctypes.data,
+                                        ktab.ctypes.data, b_out.ctypes.data) == 0
+w = rng.standard_normal((5, 27)).astype(np.float32)
+v4 = [rng.uniform(0.5, 2.0, (5,)).astype(np.float32) for _ in range(4)]
+sh = np.empty((5,), dtype=np.float32)
+assert lib.dp_fold_frozen_bn(w.ctypes.data, 5, 27, v4[0].ctypes.data, v4[1].ctypes.data, v4[2].ctypes.data, v4[3].ctypes.data, 1e-5,
+                             w.ctypes.data, sh.ctypes.data) == 0
+taps = np.empty((9, 2), dtype=np.int32)
+pos = np.empty((9,), dtype=np.int32)
+assert lib.dp_conv_taps(3, 3, 56, 56, 1, 28, 28, taps.ctypes.data, pos.ctypes.data) == 1
+print("asan driver ok")
