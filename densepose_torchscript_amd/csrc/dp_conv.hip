@@ -52,6 +52,9 @@ struct ConvArgs {
   int M, tiles_n, n_ktiles, HoWo, n_tiles;
   unsigned in_bytes, w_bytes, res_bytes;   // buffer-resource extents (ring / streaming kernels)
   int ntaps, out_linear, res_linear;
+  const void* head_w;     // fused 1x1 head (RPN): plain [16][Cout] storage type, rows = head channels
+  const float* head_b;    // [16]
+  float* head_out;        // [M][16] fp32
 };
 
 // 16 zero bytes in global memory: out-of-image / K-padding chunks are loaded from here, so every staging load is
@@ -498,6 +501,69 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
   for (; s < ns; s += 2) {        // tail: the generic step (conditional staging / counted waits)
     DP_RING_STEP(s, fpA, fcA, fpB, fcB);
     if (s + 1 < ns) DP_RING_STEP(s + 1, fpB, fcB, fpA, fcA);
+  }
+
+  // ---- fused 1x1 head (the RPN's objectness + anchor-delta convolutions, rpn.py:168-171, on the 3x3 conv's ReLU output):
+  // head[16][px] = Wh[16][256] . relu(acc + bias). The permuted accumulator layout makes run h of pixel tile j, rounded to
+  // the storage type, the B fragment of K step h (channels wc*64 + h*32 ..) of that product (dp_bottleneck.hip uses the same
+  // property), so every wave contracts ITS 64 channels with two MFMAs per pixel tile. The four channel blocks (waves wc =
+  // 0..3 of a pixel half) are chained THROUGH the accumulator: wave wc starts from wave wc-1's partial sums (handed over in
+  // LDS), so the head is accumulated over K planes 0..7 in order - bit-identical to the separate 1x1 launch it replaces,
+  // whatever kernel that launch would use for another batch size.
+  if constexpr (WC == 4 && sizeof(T) == 2) {
+    if (p.head_out != nullptr) {
+      const T* __restrict__ hw = reinterpret_cast<const T*>(p.head_w) + fr * p.Cout + n0 + wc * 64 + fq * 8;
+      const u32x4 hw0 = *reinterpret_cast<const u32x4*>(hw), hw1 = *reinterpret_cast<const u32x4*>(hw + 32);
+      float bias[2][8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float* bp = p.bias + n0 + wc * 64 + h * 32 + fq * 8;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { bias[h][k] = b0[k]; bias[h][4 + k] = b1[k]; }
+      }
+      u32x4 bf[2][TP];   // this wave's 64 channels of the hidden tensor, as the head product's B fragments
+#pragma unroll
+      for (int j = 0; j < TP; ++j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[k] = fmaxf(acc[2 * h][j][k] + bias[h][k], 0.f);
+            v[4 + k] = fmaxf(acc[2 * h + 1][j][k] + bias[h][4 + k], 0.f);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) bf[h][j][k] = Elem<T>::pack2(v[2 * k], v[2 * k + 1]);
+        }
+      }
+      // every wave has finished reading the operand ring before it is reused for the hand-over
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      f32x4* const red = reinterpret_cast<f32x4*>(smem) + (wp * TP) * 64 + lane;   // [pixel half][TP][64 lanes]
+      const f32x4 hb = *reinterpret_cast<const f32x4*>(p.head_b + fq * 4);
+#pragma unroll
+      for (int stage = 0; stage < 4; ++stage) {
+        if (wc == stage) {
+#pragma unroll
+          for (int j = 0; j < TP; ++j) {
+            f32x4 part = stage == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : red[j * 64];
+            Mma<T>::run(hw0, bf[0][j], part);
+            Mma<T>::run(hw1, bf[1][j], part);
+            if (stage < 3) {
+              red[j * 64] = part;
+            } else {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) part[k] += hb[k];
+              const int m = m0 + wp * TP * 16 + j * 16 + fr;
+              if (m < p.M) *reinterpret_cast<f32x4*>(p.head_out + (long long)m * 16 + fq * 4) = part;
+            }
+          }
+        }
+        if (stage < 3) __syncthreads();
+      }
+      if (p.out == nullptr) return;
+    }
   }
 
   // ---- epilogue straight from the accumulators ----
@@ -1010,7 +1076,7 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   DP_REQUIRE(p->N >= 0 && p->H > 0 && p->W > 0 && p->Ho > 0 && p->Wo > 0, "dp_conv2d_nhwc: bad spatial shape");
   const long long M = (long long)p->N * p->Ho * p->Wo;
   if (M == 0) return DP_OK;  // R = 0 detections is legal
-  DP_REQUIRE(p->in && p->weight && p->ktab && p->bias && p->out, "dp_conv2d_nhwc: null pointer");
+  DP_REQUIRE(p->in && p->weight && p->ktab && p->bias && (p->out || p->head_out), "dp_conv2d_nhwc: null pointer");
   DP_REQUIRE(p->Cin > 0 && p->Cin % 8 == 0, "dp_conv2d_nhwc: Cin=%d must be a positive multiple of 8", p->Cin);
   DP_REQUIRE(p->Cout > 0 && p->Cout % 8 == 0 && p->Cout <= p->Cout_w, "dp_conv2d_nhwc: Cout=%d Cout_w=%d", p->Cout, p->Cout_w);
   DP_REQUIRE(p->Cout_w % 128 == 0, "dp_conv2d_nhwc: Cout_w=%d must be a multiple of 128", p->Cout_w);
@@ -1028,10 +1094,17 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   a.w_bytes = (unsigned)((long long)p->Cout_w * p->Kpad * es);
   a.res_bytes = p->residual ? (unsigned)((long long)p->N * p->rsN * es) : 0u;
   a.ntaps = p->ntaps;
+  a.head_w = p->head_w; a.head_b = p->head_b; a.head_out = p->head_out;
   a.out_linear = (p->osH == (long long)p->Wo * p->osW && p->osN == (long long)p->Ho * p->osH) ? 1 : 0;
   a.res_linear = (p->residual && p->rshift == 0 && p->rsH == (long long)p->Wo * p->rsW && p->rsN == (long long)p->Ho * p->rsH) ? 1 : 0;
   hipStream_t s = as_stream(stream);
   const int kc = choose_conv_kernel(p, M);
+  if (p->head_out) {
+    // fused 1x1 head: the 256-cout ring kernel only (all channels of a pixel in one workgroup), 16-bit storage, ReLU hidden layer
+    DP_REQUIRE(p->head_w && p->head_b, "dp_conv2d_nhwc: head_out given without head_w / head_b");
+    if (!(kc == DP_CONV_RING256 && p->Cout == 256 && es == 2 && p->relu && !p->residual && !p->out_f32))
+      return dp_fail(DP_ERR_UNSUPPORTED, "dp_conv2d_nhwc: the fused head needs the 256-cout ring kernel (Cout 256, 16-bit storage, ReLU, no residual)");
+  }
   if (kc == DP_CONV_STREAM) {
     a.tiles_n = p->Cout / 256;
     a.n_tiles = 0;

@@ -78,6 +78,7 @@ class Engine:
         self.prof = None  # list of (kernel class, algorithmic flops, start event, end event) when profiling
         self.use_graphs = False
         self.nms_reference = "cpu"    # "cpu" | "cuda": which torchvision batched_nms strategy switch to reproduce (see above)
+        self.fuse_rpn_head = True     # RPN 3x3 conv + 1x1 heads in one launch where the 256-cout ring kernel runs the level
         self.fuse_bottleneck = True   # res2 blocks: conv2 -> conv3 -> next conv1 in one launch (bottleneck_tail)
         self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
         self._side_streams = {}
@@ -96,9 +97,11 @@ class Engine:
         return torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
 
     def conv(self, layer, x, relu=False, residual=None, rshift=0, out_f32=False, out=None, out_c_stride=None, out_c_off=0,
-             out_geom=None, out_hw=None):
+             out_geom=None, out_hw=None, head=None):
         """x: Act. Returns Act. out_geom: (osN, osH, osW, base_elems) override for the sub-pixel deconv; out_hw: (Ho, Wo)
-        override (the paired-pixel stem, whose input is narrower than its output is wide)."""
+        override (the paired-pixel stem, whose input is narrower than its output is wide). head: (weight [16, Cout], bias [16],
+        macs per pixel) of a fused 1x1 head on this layer's ReLU output - the call then returns the HEAD's fp32 output
+        [N, Ho, Wo, 16] and the hidden tensor is never written (caller checks head_fusable first)."""
         p = L.ConvParams()
         N, H, W = x.N, x.H, x.W
         assert x.C == layer.cin, (layer.name, x.C, layer.cin)
@@ -112,12 +115,19 @@ class Engine:
             Ho, Wo = out_hw
         cs = out_c_stride or layer.cout
         odt = torch.float32 if out_f32 else self.tdt
-        if out is None:
+        head_out = None
+        if head is not None:
+            head_out = self._empty((N, Ho, Wo, 16), torch.float32)
+            p.head_w, p.head_b, p.head_out = head[0].data_ptr(), head[1].data_ptr(), head_out.data_ptr()
+        elif out is None:
             out = self._empty((N, Ho, Wo, cs), odt)
         p.in_, p.weight, p.ktab, p.bias = x.t.data_ptr(), layer.weight.data_ptr(), layer.ktab.data_ptr(), layer.bias.data_ptr()
         p.residual = residual.t.data_ptr() if residual is not None else None
-        es_out = out.element_size()
-        if out_geom is None:
+        es_out = out.element_size() if out is not None else x.t.element_size()
+        if head is not None:
+            p.out = None
+            p.osN, p.osH, p.osW = Ho * Wo * cs, Wo * cs, cs
+        elif out_geom is None:
             p.out = out.data_ptr() + out_c_off * es_out
             p.osN, p.osH, p.osW = Ho * Wo * cs, Wo * cs, cs
         else:
@@ -138,7 +148,7 @@ class Engine:
         p.dtype = self.dt
         p.out_f32 = 1 if out_f32 else 0
         p.hi_off, p.wi_off = layer.hi_off, layer.wi_off
-        flops = 2 * layer.macs_per_pixel * N * Ho * Wo
+        flops = 2 * (layer.macs_per_pixel + (head[2] if head is not None else 0)) * N * Ho * Wo
         if self.prof is not None and N * Ho * Wo > 0:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
@@ -150,11 +160,28 @@ class Engine:
             es = x.t.element_size()
             nbytes = (N * (H * W if s == 1 else Ho * Wo * min(layer.ntaps, s * s)) * x.C * es + layer.weight.numel() * es
                       + N * Ho * Wo * layer.cout * (es_out + (es if residual is not None else 0) // (4 if rshift else 1)))
-            self.prof.append((cls, flops, e0, e1, "%s %dx%dx%d->%d t%d" % (layer.name, Ho, Wo, x.C, layer.cout, layer.ntaps), nbytes))
+            if head is not None:   # the hidden tensor is never written; the head's 16 fp32 channels are
+                nbytes += N * Ho * Wo * (16 * 4 - layer.cout * es_out)
+            self.prof.append((cls, flops, e0, e1, "%s%s %dx%dx%d->%d t%d" % (layer.name, "+head" if head is not None else "", Ho, Wo, x.C,
+                                                                             layer.cout, layer.ntaps), nbytes))
         else:
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
         self.flops_last += flops
+        if head is not None:
+            return Act(head_out, N, Ho, Wo, 16)
         return Act(out, N, Ho, Wo, cs)
+
+    def head_fusable(self, layer, x):
+        """True when dp_conv2d_nhwc can apply a fused 1x1 head in this layer's epilogue for input x: the launch lands on the
+        256-cout LDS-ring kernel (all 256 channels of a pixel in one workgroup), 16-bit storage."""
+        if self.dt == L.DP_F32 or layer.cout != 256 or layer.stride != 1 or not self.fuse_rpn_head:
+            return False
+        p = L.ConvParams()
+        p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout = x.N, x.H, x.W, x.C, x.H, x.W, layer.cout
+        p.Cout_w, p.Kpad, p.stride, p.ntaps, p.dtype = layer.cout_w, layer.kpad, 1, layer.ntaps, self.dt
+        p.hi_off, p.wi_off = layer.hi_off, layer.wi_off
+        p.osN, p.osH, p.osW = x.H * x.W * layer.cout, x.W * layer.cout, layer.cout
+        return self.lib.dp_conv2d_kernel_class(C.byref(p)) == 2
 
     def bottleneck_tail(self, l2, l3, l1n, t1, residual):
         """conv2 -> conv3 (+ residual, ReLU) -> conv1 of the next block in one launch (dp_bottleneck_tail_nhwc).
@@ -279,8 +306,13 @@ class Engine:
         heads, wss = [], []
         for li, k in enumerate(("p2", "p3", "p4", "p5", "p6")):
             f = feats[k]
-            t = self.conv(Ls["rpn_conv"], f, relu=True)
-            head = self.conv(Ls["rpn_head"], t, out_f32=True)
+            hp = self.model.rpn_head_plain
+            if hp is not None and self.head_fusable(Ls["rpn_conv"], f):
+                # 3x3 conv + ReLU + the two 1x1 heads in one launch: the 256-channel hidden tensor is never written (rpn.py:168-171)
+                head = self.conv(Ls["rpn_conv"], f, relu=True, head=(hp[0], hp[1], Ls["rpn_head"].macs_per_pixel))
+            else:
+                t = self.conv(Ls["rpn_conv"], f, relu=True)
+                head = self.conv(Ls["rpn_head"], t, out_f32=True)
             heads.append(head)
             ws = self._empty((self.lib.dp_rpn_topk_workspace_bytes(n, f.H, f.W, A),), torch.uint8)
             wss.append(ws)
@@ -537,7 +569,7 @@ class Engine:
             pinned.copy_(st["det_counts"], non_blocking=True)
         else:
             # everything that changes the captured launch sequence is part of the key
-            key = (tuple(images_u8.shape), slot, self.overlap_decoder, self.fuse_bottleneck, self.nms_reference)
+            key = (tuple(images_u8.shape), slot, self.overlap_decoder, self.fuse_bottleneck, self.fuse_rpn_head, self.nms_reference)
             entry = self._graphs.pop(key, None)
             if entry is None:
                 while len(self._graphs) >= MAX_GRAPHS:      # drop the least recently used graph and its memory pool

@@ -194,6 +194,16 @@ class PackedModel:
         bcat = np.concatenate([st[pg + "objectness_logits.bias"], st[pg + "anchor_deltas.bias"]]).astype(np.float32)
         L["rpn_head"] = conv_from_oihw("rpn_head", w, bcat, F, 1, 0, 1, dtype, device)
         self.rpn_head_c = L["rpn_head"].cout
+        # the same head as a plain [16][F] matrix (+ bias) for the fused form: dp_conv2d_nhwc's head_w / head_b, applied inside
+        # the 3x3 conv's epilogue where the 256-cout ring kernel runs the level (engine.rpn)
+        self.rpn_head_plain = None
+        if self.rpn_head_c == 16 and dtype != DP_F32:
+            wp = np.zeros((16, F), dtype=np.float32)
+            wp[: w.shape[0], : w.shape[1]] = w.reshape(w.shape[0], -1)
+            bp = np.zeros((16,), dtype=np.float32)
+            bp[: bcat.shape[0]] = bcat
+            tdt = torch.bfloat16 if dtype == DP_BF16 else torch.float16
+            self.rpn_head_plain = (torch.from_numpy(wp).to(tdt).to(device).contiguous(), torch.from_numpy(bp).to(device))
         # box head: fc1 K permuted (c, y, x) -> (y, x, c) over the ALLOCATED channel count
         P = cfg.box_pool
         w1 = st["roi_heads.box_head.fc1.weight"].astype(np.float32)
@@ -263,4 +273,6 @@ class PackedModel:
             out += [l.weight, l.ktab, l.bias]
         for k in sorted(getattr(self, "gn", {})):
             out += list(self.gn[k])
+        if self.rpn_head_plain is not None:
+            out += list(self.rpn_head_plain)
         return out

@@ -88,6 +88,13 @@ typedef struct {
   int32_t out_f32;       /* 1: out is fp32 regardless of dtype */
   int32_t hi_off, wi_off; /* input pixel of output (ho,wo), tap (dy,dx): (ho*stride + hi_off + dy, wo*stride_w + wi_off + dx) */
   int32_t stride_w;       /* horizontal stride; 0 = same as `stride` (only the paired-pixel stem uses stride 2 x 1) */
+  /* Optional fused 1x1 head on the ReLU output of this convolution (rpn.py:168-171: objectness_logits + anchor_deltas on
+   * relu(conv(x))): head_out[m][0..15] = head_w[16][Cout] . relu(conv + bias)[m] + head_b, the hidden tensor rounded to the
+   * storage type as if it had been stored. Needs dp_conv2d_kernel_class() == 2 with Cout == 256, 16-bit storage, relu = 1,
+   * no residual (else DP_ERR_UNSUPPORTED); `out` may then be NULL: the hidden tensor is never written. */
+  const void* head_w;     /* [16][Cout] dtype, plain row-major (rows = head channels, zero rows for unused ones) */
+  const float* head_b;    /* [16] */
+  float* head_out;        /* [N*Ho*Wo][16] fp32 */
 } dp_conv_params;
 int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
 /* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile,

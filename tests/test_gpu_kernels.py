@@ -349,6 +349,48 @@ def test_paired_preprocess_and_stem(eng, dt, shape):
     assert layer.kpad == (224 if dt == "fp32" else 256) and layer.macs_per_pixel == 16 * 147   # 7 x 4 taps x 8, padded to 128 B
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("tp", [None, "4", "5", "6", "7"])          # every tile height of the 256-cout ring kernel
+@pytest.mark.parametrize("shape", [(1, 40, 56), (2, 13, 21), (3, 9, 11), (1, 50, 84)])
+def test_conv_with_fused_rpn_head(eng, dt, tp, shape, monkeypatch):
+    """RPN head (rpn.py:168-171: 3x3 conv + ReLU, then the 1x1 objectness / anchor-delta convolutions) in ONE launch: the head is
+    applied in the ring kernel's epilogue and the 256-channel hidden tensor is never written. BIT-identical to the two-launch
+    form (same rounded hidden tensor, head accumulated over the K planes in the same order - the four 64-channel blocks are
+    chained through the accumulator), and close to torch in fp64."""
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    e = eng[dt]
+    monkeypatch.setenv("DP_CONV_BIG", "1")       # the 256-cout ring kernel whatever the tile count
+    if tp:
+        monkeypatch.setenv("DP_CONV_TP", tp)
+    N, H, W = shape
+    g = torch.Generator().manual_seed(N * 100 + H + W)
+    x = _round(torch.randn((N, 256, H, W), generator=g), dt)
+    w = _round(torch.randn((256, 256, 3, 3), generator=g) * (1.0 / 2304) ** 0.5, dt)
+    b = torch.randn((256,), generator=g) * 0.3
+    wh = _round(torch.randn((15, 256, 1, 1), generator=g) * (1.0 / 256) ** 0.5, dt)
+    bh = torch.randn((15,), generator=g)
+    conv = conv_from_oihw("rpn_conv", w.numpy(), b.numpy(), 256, 1, 1, 1, e.dt, e.device)
+    headl = conv_from_oihw("rpn_head", wh.numpy(), bh.numpy(), 256, 1, 0, 1, e.dt, e.device)
+    whp = torch.zeros((16, 256))
+    whp[:15] = wh.view(15, 256)
+    bhp = torch.zeros((16,))
+    bhp[:15] = bh
+    xa = Act(_nhwc(x, 256, e.tdt, e.device), N, H, W, 256)
+    assert e.head_fusable(conv, xa)
+    hidden = e.conv(conv, xa, relu=True)
+    want = e.conv(headl, hidden, out_f32=True)
+    got = e.conv(conv, xa, relu=True, head=(whp.to(e.tdt).to(e.device), bhp.to(e.device), 15 * 256))
+    torch.cuda.synchronize()
+    assert got.t.shape == want.t.shape == (N, H, W, 16) and got.t.dtype == torch.float32
+    assert torch.equal(got.t, want.t)
+    assert float(got.t[..., 15].abs().max()) == 0.0
+    hid = _round(F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).float(), dt).double()
+    ref = F.conv2d(hid, wh.double(), bh.double()).permute(0, 2, 3, 1)
+    ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    assert float((got.t[..., :15].double().cpu() - ref).abs().max()) <= 4 * ulp * max(float(ref.abs().max()), 1.0)
+
+
 def test_conv_fpn_lateral_plus_nearest_upsample(eng):
     from densepose_torchscript_amd.engine import Act
     from densepose_torchscript_amd.pack import conv_from_oihw
