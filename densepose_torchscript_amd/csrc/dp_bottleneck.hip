@@ -23,6 +23,7 @@
 // ragged tail are out-of-range buffer offsets (loads return 0, stores are dropped). One workgroup of 4 waves per CU.
 #include "dp_common.h"
 #include "dp_mma.h"
+#include <stdlib.h>
 
 #ifndef DP_EXP
 #define DP_EXP 0
@@ -320,6 +321,302 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bottleneck_tail64_kernel(cons
   }
 }
 
+// =====================================================================================================
+// Strip walker: the same chain, with every byte of t1 / residual / output moved in whole 128-byte lines.
+//
+// The tile kernel above loads conv2's operand as MFMA fragments (16 pixels x 64 bytes per instruction, 18 per tile) and the
+// residual / output as 64-byte runs: 36 KB of vector-memory traffic per 16-pixel tile of which 18 KB re-read t1 nine times.
+// A CU sustains only ~25 one-KiB vector-memory instructions per microsecond on such streams (PMC: the TA command / address
+// FIFOs are full 30 % of the time, profiles/r2_*), so that traffic - not HBM - bounded the kernel at 3.5 TB/s.
+//
+// Here a wave walks DOWN a 16-pixel-wide column strip of one image, L rows per job:
+//   * t1 is read once per row in its natural layout (18 pixels x 128 B = the strip plus one halo pixel each side, three
+//     whole-line loads, 8 pixels each); the wave keeps the rows r-1, r, r+1 in registers and loads only row r+2 per step.
+//     Zero padding is decided at the load (out-of-range buffer offsets return 0): no per-fragment masking at all.
+//   * a 2.25 KiB per-wave LDS buffer turns a natural-layout row into the 6 MFMA B fragments of a kernel row (3 column taps x
+//     2 channel blocks, the column shift is an LDS address offset), the residual's whole lines into the epilogue's runs and
+//     the epilogue's runs back into whole lines for the stores. It is wave-private (LDS requests of one wave execute in
+//     order): no barrier anywhere in the loop. Chunk c of pixel p sits at slot c ^ (p & 7): every access pattern used here
+//     (line-shaped stores / loads, fragment-shaped loads / stores at any pixel shift) is bank-conflict free.
+//   * per 16 pixels: 3 + 8 + 8 + 2 = 21 full-line vector-memory instructions instead of 36 fragment-shaped ones.
+// K order, rounding points and arithmetic are those of the tile kernel: results stay bit-identical to the layer-by-layer path.
+// =====================================================================================================
+constexpr int kStripBuf = 18 * 128;                     // per-wave row buffer: 18 pixels x 64 channels
+constexpr int kStripLds = kTailLds + 8 * kStripBuf;     // 159,232 B of the 163,840 B a workgroup may use
+
+struct StripArgs {
+  TailArgs t;
+  int n_strips, n_seg, seg_rows, n_jobs;
+};
+
+template <typename T, bool HAS_NEXT>
+__global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripArgs sa) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int NW = 8;
+  constexpr int NSTEP = HAS_NEXT ? 34 : 26;
+  const TailArgs& p = sa.t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const w2_s = smem;
+  unsigned char* const w3_s = smem + kTailW2;
+  unsigned char* const w1_s = smem + kTailW2 + kTailW3;
+  float* const b2_s = reinterpret_cast<float*>(smem + kTailW2 + kTailW3 + kTailW1);
+  float* const b3_s = b2_s + 64;
+  float* const b1_s = b3_s + 256;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* const buf = smem + kTailLds + wave * kStripBuf;
+
+  {  // weights -> LDS, once (same images as the tile kernel)
+    const int srow = lane >> 2;
+    const int scc = (lane & 3) ^ swz(srow);
+    const T* __restrict__ w2 = reinterpret_cast<const T*>(p.w2) + (long long)srow * p.kpad2 + scc * 8;
+    for (int piece = wave; piece < 18 * 4; piece += NW) {
+      const int pl = piece >> 2, rg = piece & 3;
+      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w2 + (long long)(rg * 16) * p.kpad2 + pl * 32),
+                                       DP_LDS_PTR(w2_s + pl * 4096 + rg * 1024), 16, 0, 0);
+    }
+    const T* __restrict__ w3 = reinterpret_cast<const T*>(p.w3) + (long long)srow * p.kpad3 + scc * 8;
+    for (int piece = wave; piece < 2 * 16; piece += NW) {
+      const int pl = piece >> 4, rg = piece & 15;
+      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w3 + (long long)(rg * 16) * p.kpad3 + pl * 32),
+                                       DP_LDS_PTR(w3_s + pl * 16384 + rg * 1024), 16, 0, 0);
+    }
+    if (HAS_NEXT) {
+      const T* __restrict__ w1 = reinterpret_cast<const T*>(p.w1n) + (long long)srow * p.kpad1n + scc * 8;
+      for (int piece = wave; piece < 8 * 4; piece += NW) {
+        const int pl = piece >> 2, rg = piece & 3;
+        __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w1 + (long long)(rg * 16) * p.kpad1n + pl * 32),
+                                         DP_LDS_PTR(w1_s + pl * 4096 + rg * 1024), 16, 0, 0);
+      }
+    }
+    if (tid < 64) b2_s[tid] = p.b2[tid];
+    if (tid < 256) b3_s[tid] = p.b3[tid];
+    if (HAS_NEXT && tid < 64) b1_s[tid] = p.b1n[tid];
+  }
+  __syncthreads();  // (vmcnt(0) + barrier) - the only workgroup barrier of the kernel
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rd = fr * 64 + ((fq ^ swz(fr)) << 4);   // weight fragment read offset inside a 16-row group of a plane
+  const int ps = lane >> 3, ci = lane & 7;          // line-shaped accesses: 8 lanes per pixel, 16-byte chunk ci of its 128 bytes
+  // the three column taps of conv2 (pack.py enumerates the 3 x 3 taps row-major; tap-major K): this kernel needs the plain
+  // 3 x 3, pad 1 geometry - column displacement -1, 0, +1 and row displacement -1, 0, +1 (checked on the host)
+  const __amdgpu_buffer_rsrc_t rs_t1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.t1), 0, p.t1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_t1n = __builtin_amdgcn_make_buffer_rsrc(HAS_NEXT ? p.t1n : p.out, 0, HAS_NEXT ? p.t1n_bytes : 0u, 0x00020000);
+  constexpr int OOB = (int)0x80000000;
+
+  // LDS addresses inside the wave's buffer. Line shape: lane = (pixel slot ps, chunk ci), instruction i covers pixels 8i + ps.
+  // Fragment shape: lane = (pixel fr, chunk 4 * half + fq). Chunk c of pixel px lives at px * 128 + ((c ^ (px & 7)) << 4).
+  int line_a[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) line_a[i] = (8 * i + ps) * 128 + ((ci ^ ps) << 4);   // (8i + ps) & 7 == ps
+  int frag_a[3][2];     // [column tap dx][channel block / run h]: pixel fr + dx
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) frag_a[dx][h] = (fr + dx) * 128 + (((h * 4 + fq) ^ ((fr + dx) & 7)) << 4);
+  // 16-pixel tensors (residual, output, next t1) use buffer pixels 0..15: fragment shape at dx = 0, line shape i = 0, 1
+
+  for (int job = blockIdx.x * NW + wave; job < sa.n_jobs; job += gridDim.x * NW) {
+    const int seg = job % sa.n_seg;
+    const int jt = job / sa.n_seg;
+    const int strip = jt % sa.n_strips;
+    const int n = jt / sa.n_strips;
+    const int r0 = seg * sa.seg_rows;
+    const int r1 = min(r0 + sa.seg_rows, p.H);
+    const int c0 = strip * 16;
+    const int img = n * p.H;
+    // per-lane column offsets (bytes), out of range -> OOB: t1 row loads (pixels c0 - 1 .. c0 + 16), 16-pixel line accesses
+    int t1_col[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int px = 8 * i + ps, wo = c0 - 1 + px;
+      t1_col[i] = (px < 18 && (unsigned)wo < (unsigned)p.W) ? wo * 128 + ci * 16 : OOB;
+    }
+    int px_col[2];      // pixel column of the 16-pixel line accesses (k = 0, 1), -1 when outside the image
+#pragma unroll
+    for (int k = 0; k < 2; ++k) px_col[k] = (c0 + 8 * k + ps < p.W) ? c0 + 8 * k + ps : -1;
+
+    auto load_row = [&](int rr, u32x4 (&dst)[3]) __attribute__((always_inline)) {
+      // rows outside the image are zero padding; rows outside [r0 - 1, r1] are never used by this job
+      const bool rok = (unsigned)rr < (unsigned)p.H && rr <= r1;
+      const int base = (img + rr) * p.W * 128;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        dst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_t1, (rok && t1_col[i] != OOB) ? base + t1_col[i] : OOB, 0, 0);
+    };
+    auto res_load = [&](int rr, int b, int k) __attribute__((always_inline)) -> u32x4 {
+      const bool ok = rr < r1 && px_col[k] >= 0;
+      return __builtin_amdgcn_raw_buffer_load_b128(rs_res, ok ? ((img + rr) * p.W + px_col[k]) * 512 + b * 128 + ci * 16 : OOB, 0, 0);
+    };
+
+    u32x4 row[4][3];     // t1 rows r-1, r, r+1 (natural layout) and the row being prefetched
+    u32x4 rres[4][2];    // residual of row r: 64-cout block b, pixel octet k (whole 128-byte lines)
+    load_row(r0 - 1, row[0]);
+    load_row(r0, row[1]);
+    load_row(r0 + 1, row[2]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) rres[b][k] = res_load(r0, b, k);
+
+    for (int r = r0; r < r1; ++r) {
+      if (!(DP_EXP & 1)) load_row(r + 2, row[3]);
+      const int orow = (img + r) * p.W;      // first pixel of this output row
+
+      u32x4 wfr[3][4];      // weight fragments: three register sets, the reads run two K steps ahead of the MFMAs
+      u32x4 bfr[3][2];      // B fragments of the kernel row being multiplied: [dx][channel block]
+      u32x4 tf[2];          // t2 (conv3's B fragments)
+      u32x4 xf[8];          // block output (conv1''s B fragments)
+      u32x4 rfr[4][2];      // residual runs of the four 64-cout blocks (fragment shape)
+      f32x4 acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wfr[0][i] = *reinterpret_cast<const u32x4*>(w2_s + i * 1024 + rd);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wfr[1][i] = *reinterpret_cast<const u32x4*>(w2_s + 4096 + i * 1024 + rd);
+
+      // natural-layout t1 row dy -> LDS -> the 6 fragments of kernel row dy
+      auto stage_row = [&](const u32x4 (&src)[3]) __attribute__((always_inline)) {
+        *reinterpret_cast<u32x4*>(buf + line_a[0]) = src[0];
+        *reinterpret_cast<u32x4*>(buf + line_a[1]) = src[1];
+        if (ps < 2) *reinterpret_cast<u32x4*>(buf + line_a[2]) = src[2];     // pixels 16, 17 (the buffer ends there)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) bfr[dx][cb] = *reinterpret_cast<const u32x4*>(buf + frag_a[dx][cb]);
+      };
+      // whole lines of the finished 64-cout block bb: LDS (fragment shape, written by the epilogue) -> line shape -> store
+      auto flush_out = [&](int bb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const u32x4 ln = *reinterpret_cast<const u32x4*>(buf + line_a[k]);
+          if (!(DP_EXP & 4) || ln[0] == 0x12345678u)
+            __builtin_amdgcn_raw_buffer_store_b128(ln, rs_out, px_col[k] >= 0 ? (orow + px_col[k]) * 512 + bb * 128 + ci * 16 : OOB, 0, 0);
+        }
+      };
+      stage_row(row[0]);
+
+      static_for<0, NSTEP>([&](auto kk) {
+        constexpr int K = decltype(kk)::value;
+        u32x4 (&wf)[4] = wfr[K % 3];
+        if constexpr (K + 2 < NSTEP) {   // weight fragments of step K + 2 fly while the MFMAs of steps K and K + 1 run
+          const unsigned char* nx = tail_wfrag_addr<K + 2>(w2_s, w3_s, w1_s) + rd;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) wfr[(K + 2) % 3][i] = *reinterpret_cast<const u32x4*>(nx + i * 1024);
+        }
+        if constexpr (K == 0 || (K >= 18 && ((K - 18) & 1) == 0 && K < 26) || K == 26) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (K < 18) {
+          // ---- conv2, K plane K = (kernel row dy, column tap dx, channel block cb)
+          constexpr int dy = K / 6, dx = (K % 6) >> 1, cb = K & 1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) Mma<T>::run(wf[i], bfr[dx][cb], acc[i]);
+          if constexpr (K >= 1 && K <= 4) {
+            // residual of 64-cout block K - 1 (the buffer is idle between two kernel rows): whole lines -> LDS -> the two
+            // runs this lane adds in conv3's epilogue; the line registers are refilled with the next row's residual
+            constexpr int b = K - 1;
+            *reinterpret_cast<u32x4*>(buf + line_a[0]) = rres[b][0];
+            *reinterpret_cast<u32x4*>(buf + line_a[1]) = rres[b][1];
+            rfr[b][0] = *reinterpret_cast<const u32x4*>(buf + frag_a[0][0]);
+            rfr[b][1] = *reinterpret_cast<const u32x4*>(buf + frag_a[0][1]);
+            if (!(DP_EXP & 2)) {
+              rres[b][0] = res_load(r + 1, b, 0);
+              rres[b][1] = res_load(r + 1, b, 1);
+            }
+          }
+          if constexpr (K % 6 == 5 && dy < 2) stage_row(row[dy + 1]);     // next kernel row (its reads land during the MFMAs above)
+          if constexpr (K == 17) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const f32x4 b0 = *reinterpret_cast<const f32x4*>(b2_s + h * 32 + fq * 8);
+              const f32x4 b1 = *reinterpret_cast<const f32x4*>(b2_s + h * 32 + fq * 8 + 4);
+              float v[8];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                v[k] = fmaxf(acc[2 * h][k] + b0[k], 0.f);
+                v[4 + k] = fmaxf(acc[2 * h + 1][k] + b1[k], 0.f);
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) tf[h][k] = Elem<T>::pack2(v[2 * k], v[2 * k + 1]);
+            }
+          }
+        } else if constexpr (K < 26) {
+          // ---- conv3, 64-cout block b, K plane sp
+          constexpr int b = (K - 18) >> 1, sp = (K - 18) & 1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) Mma<T>::run(wf[i], tf[sp], acc[i]);
+          if constexpr (sp == 0 && b > 0) flush_out(b - 1);      // the previous block's lines, one step after they were written
+          if constexpr (sp == 1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              constexpr int qb = 2 * b;
+              const int q = qb + h;
+              const f32x4 b0 = *reinterpret_cast<const f32x4*>(b3_s + q * 32 + fq * 8);
+              const f32x4 b1 = *reinterpret_cast<const f32x4*>(b3_s + q * 32 + fq * 8 + 4);
+              float v[8];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                v[k] = acc[2 * h][k] + b0[k];
+                v[4 + k] = acc[2 * h + 1][k] + b1[k];
+              }
+              const u32x4 rv = rfr[b][h];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                v[2 * k] += Elem<T>::unpack(rv[k] & 0xffffu);
+                v[2 * k + 1] += Elem<T>::unpack(rv[k] >> 16);
+              }
+              u32x4 pk;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) pk[k] = Elem<T>::pack2(fmaxf(v[2 * k], 0.f), fmaxf(v[2 * k + 1], 0.f));
+              xf[q] = pk;
+              *reinterpret_cast<u32x4*>(buf + frag_a[0][h]) = pk;      // runs -> LDS (-> whole lines in flush_out)
+            }
+            if constexpr (b == 3 && !HAS_NEXT) flush_out(3);
+          }
+        } else {
+          // ---- conv1' of the next block: K = the 256 channels just produced (plane q = run q above)
+          constexpr int q = K - 26;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) Mma<T>::run(wf[i], xf[q], acc[i]);
+          if constexpr (q == 0) flush_out(3);
+          if constexpr (q == 7) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const f32x4 b0 = *reinterpret_cast<const f32x4*>(b1_s + h * 32 + fq * 8);
+              const f32x4 b1 = *reinterpret_cast<const f32x4*>(b1_s + h * 32 + fq * 8 + 4);
+              float v[8];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                v[k] = fmaxf(acc[2 * h][k] + b0[k], 0.f);
+                v[4 + k] = fmaxf(acc[2 * h + 1][k] + b1[k], 0.f);
+              }
+              u32x4 pk;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) pk[k] = Elem<T>::pack2(v[2 * k], v[2 * k + 1]);
+              *reinterpret_cast<u32x4*>(buf + frag_a[0][h]) = pk;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const u32x4 ln = *reinterpret_cast<const u32x4*>(buf + line_a[k]);
+              if (!(DP_EXP & 4) || ln[0] == 0x12345678u)
+                __builtin_amdgcn_raw_buffer_store_b128(ln, rs_t1n, px_col[k] >= 0 ? (orow + px_col[k]) * 128 + ci * 16 : OOB, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // the three live rows slide down by one
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { row[0][i] = row[1][i]; row[1][i] = row[2][i]; row[2][i] = row[3][i]; }
+    }
+  }
+}
+
 static int tail_num_cus() {
   int dev = 0;
   hipDeviceProp_t prop;
@@ -344,6 +641,36 @@ int launch_tail(const TailArgs& a, hipStream_t stream) {
   if (gx > (n_wt + NW - 1) / NW) gx = (n_wt + NW - 1) / NW;
   hipLaunchKernelGGL((bottleneck_tail64_kernel<T, HAS_NEXT, NW, TP>), dim3(gx), dim3(NW * 64), kTailLds, stream, a);
   return dp_check_launch("bottleneck_tail64_kernel");
+}
+
+template <typename T, bool HAS_NEXT>
+int launch_strip(const TailArgs& a, hipStream_t stream) {
+  static bool attr_set = false;
+  static int cus = 0;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_strip64_kernel<T, HAS_NEXT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kStripLds);
+    cus = tail_num_cus();
+    attr_set = true;
+  }
+  StripArgs sa;
+  sa.t = a;
+  sa.n_strips = (a.W + 15) / 16;
+  // rows per job: about two jobs per wave of a full chip (each job re-reads one halo row above and below its rows), at
+  // least 4 rows; the split does not touch the arithmetic of a pixel, so results do not depend on it
+  const long long cols = (long long)a.N * sa.n_strips;
+  long long want = (2ll * cus * 8 + cols - 1) / cols;
+  if (want < 1) want = 1;
+  int seg_rows = (int)((a.H + want - 1) / want);
+  if (seg_rows < 4) seg_rows = a.H < 4 ? a.H : 4;
+  sa.seg_rows = seg_rows;
+  sa.n_seg = (a.H + seg_rows - 1) / seg_rows;
+  const long long jobs = cols * sa.n_seg;
+  sa.n_jobs = (int)jobs;
+  int gx = (int)((jobs + 7) / 8);
+  if (gx > cus) gx = cus;
+  hipLaunchKernelGGL((bottleneck_strip64_kernel<T, HAS_NEXT>), dim3(gx), dim3(512), kStripLds, stream, sa);
+  return dp_check_launch("bottleneck_strip64_kernel");
 }
 
 }  // namespace
@@ -385,6 +712,14 @@ extern "C" int dp_bottleneck_tail_nhwc(const dp_bottleneck_params* p, dp_stream_
   a.hi_off = p->hi_off2; a.wi_off = p->wi_off2;
   a.t1_bytes = (unsigned)(M * 128); a.out_bytes = (unsigned)(M * 512); a.t1n_bytes = (unsigned)(M * 128);
   hipStream_t s = as_stream(stream);
+  // two kernels for the same arithmetic: the strip walker (whole-line memory traffic, default whenever conv2 is the plain
+  // 3x3 / pad 1 it is written for) and the tile kernel (any tap offsets; DP_TAIL_KERNEL=tile selects it for A/B runs)
+  const char* ke = getenv("DP_TAIL_KERNEL");
+  const bool strip = !(ke && ke[0] == 't') && p->hi_off2 == -1 && p->wi_off2 == -1 && (long long)p->N * ((p->W + 15) / 16) * p->H < (1ll << 30);
+  if (strip) {
+    if (p->dtype == DP_BF16) return p->next_t1 ? launch_strip<uint16_t, true>(a, s) : launch_strip<uint16_t, false>(a, s);
+    return p->next_t1 ? launch_strip<f16_t, true>(a, s) : launch_strip<f16_t, false>(a, s);
+  }
   if (p->dtype == DP_BF16) return p->next_t1 ? launch_tail<uint16_t, true>(a, s) : launch_tail<uint16_t, false>(a, s);
   return p->next_t1 ? launch_tail<f16_t, true>(a, s) : launch_tail<f16_t, false>(a, s);
 }

@@ -21,6 +21,7 @@ groups=(
 )
 i=0
 for g in "${groups[@]}"; do
+  if [ -n "$PMC_MAX" ] && [ $i -ge $PMC_MAX ]; then break; fi
   timeout 150 rocprofv3 --kernel-trace --pmc $g -d $out/p$i --output-format csv -- "$@" > $out/p$i.log 2>&1
   i=$((i+1))
 done

@@ -25,6 +25,11 @@ def short(name):
         if m.group(1) == "conv1x1_stream_kernel":
             return "conv1x1_stream_kernel[%s]" % dt
         return "conv_igemm_kernel<%s>[%s]" % (args[1], dt)
+    m = re.search(r"bottleneck_tail64_kernel<([^>]*)>", name)
+    if m:
+        args = [a.strip() for a in m.group(1).split(",")]
+        dt = {"unsigned short": "bf16", "_Float16": "f16"}.get(args[0], args[0])
+        return "bottleneck_tail64_kernel<%s>[%s]" % ("next" if args[1] == "true" else "last", dt)
     m = re.search(r"::(\w+)(<|\()", name)
     if m:
         return m.group(1)
