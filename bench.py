@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="sub-batches of a step run concurrently on this many HIP streams")
     ap.add_argument("--pipeline", type=int, default=2, help="stream lanes consecutive batches alternate between (1 = off)")
     ap.add_argument("--no-overlap", action="store_true", help="decoder in line instead of on a side stream")
+    ap.add_argument("--no-fork", action="store_true", help="independent per-level layers in line instead of on forked streams")
     ap.add_argument("--no-graphs", action="store_true", help="launch every kernel eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-roofline", action="store_true", help="skip the event-instrumented roofline pass (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -202,6 +203,7 @@ def main():
     # the roofline pass use; otherwise the decoder also runs beside the RPN / box branch on a side stream
     overlap = not (args.streams == 1 and args.no_graphs) and not args.no_overlap
     eng.overlap_decoder = overlap
+    eng.fork_levels = eng.fork_levels if (overlap and not args.no_fork) else 0
     hw = (args.height, args.width)
     frames = make_frames(args.batch, rank * args.batch, hw, device)  # weak scaling: every rank owns `batch` frames
     torch.cuda.synchronize()

@@ -78,6 +78,13 @@ class Engine:
         self.prof = None  # list of (kernel class, algorithmic flops, start event, end event) when profiling
         self.use_graphs = False
         self.nms_reference = "cpu"    # "cpu" | "cuda": which torchvision batched_nms strategy switch to reproduce (see above)
+        # independent per-level layers on forked streams, bit mask: 1 FPN output convs, 2 RPN levels, 4 decoder scale heads.
+        # Measured (bench.py, 2 runs each, same box): none 889 / 892 img/s, FPN 896 / 897, RPN 915 / 914, FPN + RPN 915 / 903;
+        # the decoder's heads fork from a stream that is itself a fork, which hipGraph capture does not survive (segfault in
+        # capture_end on ROCm 7.2) - so only the RPN levels are forked by default (DP_FORK overrides, for experiments)
+        import os as _os
+        self.fork_levels = int(_os.environ.get("DP_FORK", "2"))
+        self._forked = {}
         self.fuse_rpn_head = True     # RPN 3x3 conv + 1x1 heads in one launch where the 256-cout ring kernel runs the level
         self.fuse_bottleneck = True   # res2 blocks: conv2 -> conv3 -> next conv1 in one launch (bottleneck_tail)
         self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
@@ -92,6 +99,35 @@ class Engine:
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @contextlib.contextmanager
+    def _branch(self, i, group=1):
+        """Run the enclosed launches on side stream `i` of the current stream, forked from everything launched on it so far:
+        independent small layers (FPN output convs, RPN levels, decoder scale heads) that cannot fill the chip alone run beside
+        each other. The caller joins with _join() before anything reads their results; tensors a branch allocates and hands
+        back must be passed to _join(outputs=...). With `fork_levels` off (or while profiling) the body runs in line."""
+        if not (self.fork_levels & group) or self.prof is not None or self.trace is not None or (
+                group == 4 and torch.cuda.is_current_stream_capturing()):
+            yield
+            return
+        cur = torch.cuda.current_stream(self.device)
+        pool = self._side_streams.setdefault(("fork", cur.cuda_stream), [])
+        while len(pool) <= i:
+            pool.append(torch.cuda.Stream(device=self.device))
+        s = pool[i]
+        s.wait_stream(cur)
+        self._forked.setdefault(cur.cuda_stream, set()).add(i)
+        with torch.cuda.stream(s):
+            yield
+
+    def _join(self, outputs=()):
+        cur = torch.cuda.current_stream(self.device)
+        pool = self._side_streams.get(("fork", cur.cuda_stream), [])
+        for i in sorted(self._forked.pop(cur.cuda_stream, ())):
+            cur.wait_stream(pool[i])
+        for t in outputs:
+            if t is not None and t.is_cuda:
+                t.record_stream(cur)
 
     def _empty(self, shape, dtype=None):
         return torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
@@ -278,16 +314,28 @@ class Engine:
             res[stage] = x
         feats = {}
         with self._stage("backbone.fpn"):
+            # the top-down chain (lateral5 -> lateral4 + up -> ...) is sequential; each level's 3x3 output conv only needs its own
+            # merged map, so the small ones (p5, p4, p3) run on forked streams beside the rest of the chain
             prev = self.conv(Ls["fpn_lateral5"], res["res5"])
-            feats["p5"] = self.conv(Ls["fpn_output5"], prev)
-            for lvl in (4, 3, 2):
-                prev = self.conv(Ls["fpn_lateral%d" % lvl], res["res%d" % lvl], residual=prev, rshift=1)  # + nearest x2 of top-down
-                feats["p%d" % lvl] = self.conv(Ls["fpn_output%d" % lvl], prev)
-            p5 = feats["p5"]
-            H6, W6 = (p5.H - 1) // 2 + 1, (p5.W - 1) // 2 + 1
-            p6 = self._empty((p5.N, H6, W6, p5.C))
-            L.check(self.lib.dp_subsample2_nhwc(p5.t.data_ptr(), p6.data_ptr(), p5.N, p5.H, p5.W, p5.C, self.dt, self._stream()), "subsample2")
-            feats["p6"] = Act(p6, p5.N, H6, W6, p5.C)
+            outs = []
+            for bi, lvl in enumerate((5, 4, 3, 2)):
+                if lvl != 5:
+                    prev = self.conv(Ls["fpn_lateral%d" % lvl], res["res%d" % lvl], residual=prev, rshift=1)  # + nearest x2 of top-down
+                if lvl == 2:
+                    feats["p2"] = self.conv(Ls["fpn_output2"], prev)
+                    continue
+                with self._branch(bi, 1):
+                    feats["p%d" % lvl] = self.conv(Ls["fpn_output%d" % lvl], prev)
+                    outs.append(feats["p%d" % lvl].t)
+                    if lvl == 5:
+                        p5 = feats["p5"]
+                        H6, W6 = (p5.H - 1) // 2 + 1, (p5.W - 1) // 2 + 1
+                        p6 = self._empty((p5.N, H6, W6, p5.C))
+                        L.check(self.lib.dp_subsample2_nhwc(p5.t.data_ptr(), p6.data_ptr(), p5.N, p5.H, p5.W, p5.C, self.dt, self._stream()),
+                                "subsample2")
+                        feats["p6"] = Act(p6, p5.N, H6, W6, p5.C)
+                        outs.append(p6)
+            self._join(outs)
         return feats
 
     def rpn(self, feats, Hp, Wp):
@@ -304,15 +352,26 @@ class Engine:
         A = len(cfg.anchor_ratios)
         levels = (L.RpnLevelParams * nl)()
         heads, wss = [], []
-        for li, k in enumerate(("p2", "p3", "p4", "p5", "p6")):
-            f = feats[k]
+        def level_head(f):
             hp = self.model.rpn_head_plain
             if hp is not None and self.head_fusable(Ls["rpn_conv"], f):
                 # 3x3 conv + ReLU + the two 1x1 heads in one launch: the 256-channel hidden tensor is never written (rpn.py:168-171)
-                head = self.conv(Ls["rpn_conv"], f, relu=True, head=(hp[0], hp[1], Ls["rpn_head"].macs_per_pixel))
-            else:
-                t = self.conv(Ls["rpn_conv"], f, relu=True)
-                head = self.conv(Ls["rpn_head"], t, out_f32=True)
+                return self.conv(Ls["rpn_conv"], f, relu=True, head=(hp[0], hp[1], Ls["rpn_head"].macs_per_pixel))
+            t = self.conv(Ls["rpn_conv"], f, relu=True)
+            return self.conv(Ls["rpn_head"], t, out_f32=True)
+
+        # the five levels are independent (same weights, rpn.py:160-172): p2 on this stream, the small ones beside it
+        level_heads = {}
+        with self._branch(0, 2):
+            level_heads["p3"] = level_head(feats["p3"])
+        with self._branch(1, 2):
+            for k in ("p4", "p5", "p6"):
+                level_heads[k] = level_head(feats[k])
+        level_heads["p2"] = level_head(feats["p2"])
+        self._join([h.t for h in level_heads.values()])
+        for li, k in enumerate(("p2", "p3", "p4", "p5", "p6")):
+            f = feats[k]
+            head = level_heads[k]
             heads.append(head)
             ws = self._empty((self.lib.dp_rpn_topk_workspace_bytes(n, f.H, f.W, A),), torch.uint8)
             wss.append(ws)
@@ -402,21 +461,29 @@ class Engine:
         """roi_head.py:71-79: x = head(p2) + head(p3) + head(p4) + head(p5), each head ending in a bilinear x2 except p2's;
         the three final upsamples and the level sum run as ONE pass (dp_merge_upsample2x_nhwc, same fp32 summation order)."""
         Ls = self.model.layers
-        base, lows = None, []
-        for lvl, nconv in decoder_layout(self.cfg):
+        def scale_head(lvl, nconv):
             t = feats[lvl]
             for k in range(nconv):
                 t = self.conv(Ls["roi_heads.decoder.%s.%d" % (lvl, 2 * k)], t, relu=True)
-                if lvl == "p2":
-                    base = t
-                elif k < nconv - 1:
+                if lvl != "p2" and k < nconv - 1:
                     up = self._empty((t.N, 2 * t.H, 2 * t.W, t.C))
                     L.check(self.lib.dp_upsample_bilinear2x_nhwc(t.t.data_ptr(), up.data_ptr(), t.N, t.H, t.W, t.C, 0, self.dt,
                                                                  self._stream()), "upsample")
                     t = Act(up, t.N, 2 * t.H, 2 * t.W, t.C)
-                else:
-                    assert 2 * t.H == base.H and 2 * t.W == base.W and t.C == base.C
-                    lows.append(t)
+            return t
+
+        # the scale heads are independent until the level sum: the three small ones run beside the p2 head
+        base, lows = None, []
+        layout = decoder_layout(self.cfg)
+        for bi, (lvl, nconv) in enumerate(l for l in layout if l[0] != "p2"):
+            with self._branch(bi, 4):
+                lows.append(scale_head(lvl, nconv))
+        for lvl, nconv in layout:
+            if lvl == "p2":
+                base = scale_head(lvl, nconv)
+        self._join([t.t for t in lows])
+        for t in lows:
+            assert 2 * t.H == base.H and 2 * t.W == base.W and t.C == base.C
         arr = (C.c_void_p * len(lows))(*[t.t.data_ptr() for t in lows])
         L.check(self.lib.dp_merge_upsample2x_nhwc(base.t.data_ptr(), arr, len(lows), base.t.data_ptr(), base.N, lows[0].H, lows[0].W,
                                                   base.C, self.dt, self._stream()), "dp_merge_upsample2x_nhwc")
@@ -569,7 +636,7 @@ class Engine:
             pinned.copy_(st["det_counts"], non_blocking=True)
         else:
             # everything that changes the captured launch sequence is part of the key
-            key = (tuple(images_u8.shape), slot, self.overlap_decoder, self.fuse_bottleneck, self.fuse_rpn_head, self.nms_reference)
+            key = (tuple(images_u8.shape), slot, self.overlap_decoder, self.fuse_bottleneck, self.fuse_rpn_head, self.fork_levels, self.nms_reference)
             entry = self._graphs.pop(key, None)
             if entry is None:
                 while len(self._graphs) >= MAX_GRAPHS:      # drop the least recently used graph and its memory pool
