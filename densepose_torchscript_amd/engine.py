@@ -85,6 +85,7 @@ class Engine:
         import os as _os
         self.fork_levels = int(_os.environ.get("DP_FORK", "2"))
         self._forked = {}
+        self.fuse_stem_pool = True    # stem conv + ReLU + max-pool in one launch (dp_stem_pool_nhwc)
         self.fuse_rpn_head = True     # RPN 3x3 conv + 1x1 heads in one launch where the 256-cout ring kernel runs the level
         self.fuse_bottleneck = True   # res2 blocks: conv2 -> conv3 -> next conv1 in one launch (bottleneck_tail)
         self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
@@ -207,6 +208,31 @@ class Engine:
             return Act(head_out, N, Ho, Wo, 16)
         return Act(out, N, Ho, Wo, cs)
 
+    def stem_pool(self, layer, x):
+        """resnet.py:350-354 in one launch (dp_stem_pool_nhwc). x: the paired-pixel image [N, Hp, Wp/2 + 3, 8]. Returns the pooled
+        Act, or None when the library has no fused kernel for the shape (fp32 parity mode, tiny widths)."""
+        p = L.StemPoolParams()
+        Hp, Wp = x.H, 2 * (x.W - 3)
+        p.N, p.Hp, p.Wp, p.Cout, p.Kpad, p.dtype = x.N, Hp, Wp, layer.cout, layer.kpad, self.dt
+        if layer.stride != 2 or layer.stride_w != 1 or layer.ntaps != 28 or not self.lib.dp_stem_pool_supported(C.byref(p)):
+            return None
+        Ho, Wo = (Hp // 2 - 1) // 2 + 1, (Wp // 2 - 1) // 2 + 1
+        out = self._empty((x.N, Ho, Wo, layer.cout))
+        p.in_, p.weight, p.bias, p.out = x.t.data_ptr(), layer.weight.data_ptr(), layer.bias.data_ptr(), out.data_ptr()
+        flops = 2 * layer.macs_per_pixel * x.N * (Hp // 2) * (Wp // 2)
+        prof = self.prof is not None
+        if prof:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+        L.check(self.lib.dp_stem_pool_nhwc(C.byref(p), self._stream()), "dp_stem_pool_nhwc")
+        if prof:
+            e1.record(torch.cuda.current_stream(self.device))
+            es = out.element_size()
+            self.prof.append(("stem_pool_kernel", flops, e0, e1, "%s+maxpool %dx%d->%dx%dx%d" % (layer.name, Hp, Wp, Ho, Wo, layer.cout),
+                              x.t.numel() * es + out.numel() * es))
+        self.flops_last += flops
+        return Act(out, x.N, Ho, Wo, layer.cout)
+
     def head_fusable(self, layer, x):
         """True when dp_conv2d_nhwc can apply a fused 1x1 head in this layer's epilogue for input x: the launch lands on the
         256-cout LDS-ring kernel (all 256 channels of a pixel in one workgroup), 16-bit storage."""
@@ -288,11 +314,15 @@ class Engine:
         cfg = self.cfg
         bu = "backbone.bottom_up."
         with self._stage("backbone.stem"):
-            x = self.conv(Ls["stem"], x, relu=True, out_hw=(x.H // 2, x.W - 3))   # paired cells in, Hp/2 x Wp/2 pixels out
-            Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
-            pooled = self._empty((x.N, Ho, Wo, x.C))
-            L.check(self.lib.dp_maxpool3x3s2_nhwc(x.t.data_ptr(), pooled.data_ptr(), x.N, x.H, x.W, x.C, self.dt, self._stream()), "maxpool")
-            x = Act(pooled, x.N, Ho, Wo, x.C)
+            fused = self.stem_pool(Ls["stem"], x) if self.fuse_stem_pool else None
+            if fused is not None:
+                x = fused       # conv + FrozenBN + ReLU + max-pool in one launch: the conv output is never written
+            else:
+                x = self.conv(Ls["stem"], x, relu=True, out_hw=(x.H // 2, x.W - 3))   # paired cells in, Hp/2 x Wp/2 pixels out
+                Ho, Wo = (x.H + 2 - 3) // 2 + 1, (x.W + 2 - 3) // 2 + 1
+                pooled = self._empty((x.N, Ho, Wo, x.C))
+                L.check(self.lib.dp_maxpool3x3s2_nhwc(x.t.data_ptr(), pooled.data_ptr(), x.N, x.H, x.W, x.C, self.dt, self._stream()), "maxpool")
+                x = Act(pooled, x.N, Ho, Wo, x.C)
         res = {}
         blocks = list(resnet_blocks(cfg))
         t_next = None   # conv1 output of the coming block, when the previous block's fused tail already produced it
@@ -636,7 +666,7 @@ class Engine:
             pinned.copy_(st["det_counts"], non_blocking=True)
         else:
             # everything that changes the captured launch sequence is part of the key
-            key = (tuple(images_u8.shape), slot, self.overlap_decoder, self.fuse_bottleneck, self.fuse_rpn_head, self.fork_levels, self.nms_reference)
+            key = (tuple(images_u8.shape), slot, self.overlap_decoder, self.fuse_bottleneck, self.fuse_rpn_head, self.fuse_stem_pool, self.fork_levels, self.nms_reference)
             entry = self._graphs.pop(key, None)
             if entry is None:
                 while len(self._graphs) >= MAX_GRAPHS:      # drop the least recently used graph and its memory pool

@@ -49,6 +49,11 @@ class BottleneckParams(C.Structure):
                 ("dtype", c_i32)]
 
 
+class StemPoolParams(C.Structure):
+    _fields_ = [("in_", c_void_p), ("weight", c_void_p), ("bias", c_void_p), ("out", c_void_p),
+                ("N", c_i32), ("Hp", c_i32), ("Wp", c_i32), ("Cout", c_i32), ("Kpad", c_i32), ("dtype", c_i32)]
+
+
 class RpnLevelParams(C.Structure):
     _fields_ = [("head", c_void_p),
                 ("n_img", c_i32), ("Hi", c_i32), ("Wi", c_i32), ("A", c_i32), ("head_c", c_i32),
@@ -127,6 +132,8 @@ SYMBOLS = {
     "dp_conv2d_tile_rows": (c_int, [C.POINTER(ConvParams)]),
     "dp_bottleneck_tail_supported": (c_int, [C.POINTER(BottleneckParams)]),
     "dp_bottleneck_tail_nhwc": (c_int, [C.POINTER(BottleneckParams), c_void_p]),
+    "dp_stem_pool_supported": (c_int, [C.POINTER(StemPoolParams)]),
+    "dp_stem_pool_nhwc": (c_int, [C.POINTER(StemPoolParams), c_void_p]),
     "dp_maxpool3x3s2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_subsample2_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dp_upsample_bilinear2x_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -134,6 +134,25 @@ typedef struct {
 int dp_bottleneck_tail_supported(const dp_bottleneck_params* p);
 int dp_bottleneck_tail_nhwc(const dp_bottleneck_params* p, dp_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K3  resnet.py:350-354  BasicStem.forward in ONE launch: 7x7 stride-2 pad-3 conv + FrozenBN + ReLU + F.max_pool2d(3, 2, 1).
+ * in: the paired-pixel image of dp_preprocess_u8 (paired = 1); weight / bias: the stem packed over that layout (K = 7 kernel
+ * rows x 4 cells x 8 = 224, Kpad 256: pack.stem_paired_conv / dp_pack_conv_weights with taps (dy, dxp)). The conv output is
+ * never written. Bit-identical to dp_conv2d_nhwc + dp_maxpool3x3s2_nhwc. Fused shapes: dp_stem_pool_supported() (16-bit
+ * storage, 64 output channels); anything else returns DP_ERR_UNSUPPORTED and the caller runs the two layers.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* in;        /* [N][Hp][Wp / 2 + 3][8] dtype */
+  const void* weight;    /* [Cout_w][Kpad] dtype */
+  const float* bias;     /* [Cout_w] */
+  void* out;             /* [N][Hp / 4][Wp / 4][Cout] dtype */
+  int32_t N, Hp, Wp;     /* padded image size (multiples of 4) */
+  int32_t Cout, Kpad;
+  int32_t dtype;
+} dp_stem_pool_params;
+int dp_stem_pool_supported(const dp_stem_pool_params* p);
+int dp_stem_pool_nhwc(const dp_stem_pool_params* p, dp_stream_t stream);
+
 /* K3  resnet.py:353  F.max_pool2d(k=3, s=2, p=1), NHWC */
 int dp_maxpool3x3s2_nhwc(const void* in, void* out, int N, int H, int W, int C, int dtype, dp_stream_t stream);
 

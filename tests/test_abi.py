@@ -62,7 +62,8 @@ def test_struct_layout_matches_c(built, tmp_path):
     """sizeof() of every parameter struct as seen by a C compiler == ctypes.sizeof of its mirror."""
     import subprocess
     names = {"dp_preprocess_params": built.PreprocessParams, "dp_conv_params": built.ConvParams,
-             "dp_bottleneck_params": built.BottleneckParams,
+             "dp_bottleneck_params": built.BottleneckParams, "dp_stem_pool_params": built.StemPoolParams,
+             "dp_pack_params": built.PackParams, "dp_pack_info": built.PackInfo,
              "dp_rpn_level_params": built.RpnLevelParams, "dp_nms_params": built.NmsParams,
              "dp_roi_align_params": built.RoiAlignParams, "dp_box_decode_params": built.BoxDecodeParams,
              "dp_postprocess_params": built.PostprocessParams, "dp_iuv_params": built.IuvParams,

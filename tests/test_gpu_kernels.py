@@ -391,6 +391,50 @@ def test_conv_with_fused_rpn_head(eng, dt, tp, shape, monkeypatch):
     assert float((got.t[..., :15].double().cpu() - ref).abs().max()) <= 4 * ulp * max(float(ref.abs().max()), 1.0)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(2, 61, 90, 64, 96), (1, 64, 96, 64, 96), (3, 33, 37, 64, 64), (1, 30, 500, 32, 512), (1, 200, 230, 224, 256)])
+def test_stem_pool_fused_equals_conv_then_pool(eng, dt, shape):
+    """dp_stem_pool_nhwc (resnet.py:350-354: conv 7x7/2 + FrozenBN + ReLU + max_pool2d(3, 2, 1) in one launch) is BIT-identical to
+    dp_conv2d_nhwc + dp_maxpool3x3s2_nhwc, and agrees with torch. Shapes: several column strips (> 56 pooled columns), ragged
+    last strip, more pooled rows than one job, image narrower / shorter than its padded size."""
+    from densepose_torchscript_amd import lib as L
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import stem_paired_conv
+    e = eng[dt]
+    n, h, w, Hp, Wp = shape
+    g = torch.Generator().manual_seed(n * 100 + h + w)
+    img = torch.randint(0, 256, (n, 3, h, w), generator=g, dtype=torch.uint8)
+    mean, std = (103.53, 116.28, 123.675), (1.0, 1.0, 1.0)
+    Wq = Wp // 2 + 3
+    buf = torch.empty((n, Hp, Wq, 8), dtype=e.tdt, device=e.device)
+    p = L.PreprocessParams()
+    src = img.to(e.device)
+    p.src, p.dst, p.paired = src.data_ptr(), buf.data_ptr(), 1
+    p.n_img, p.h, p.w, p.Hp, p.Wp, p.dtype = n, h, w, Hp, Wp, e.dt
+    for i in range(3):
+        p.mean[i], p.std[i] = mean[i], std[i]
+    L.check(e.lib.dp_preprocess_u8(C.byref(p), e._stream()), "dp_preprocess_u8")
+    wt = _round(torch.randn((64, 3, 7, 7), generator=g) * 0.01, dt)
+    b = torch.randn((64,), generator=g) * 20
+    layer = stem_paired_conv("stem", wt.numpy(), b.numpy(), e.dt, e.device)
+    xa = Act(buf, n, Hp, Wq, 8)
+    conv = e.conv(layer, xa, relu=True, out_hw=(Hp // 2, Wp // 2))
+    Ho, Wo = (Hp // 2 - 1) // 2 + 1, (Wp // 2 - 1) // 2 + 1
+    want = torch.empty((n, Ho, Wo, 64), dtype=e.tdt, device=e.device)
+    assert e.lib.dp_maxpool3x3s2_nhwc(conv.t.data_ptr(), want.data_ptr(), n, Hp // 2, Wp // 2, 64, e.dt, e._stream()) == 0
+    got = e.stem_pool(layer, xa)
+    assert got is not None, "the library must have a fused kernel for the 64-channel stem"
+    torch.cuda.synchronize()
+    assert got.t.shape == want.shape
+    assert torch.equal(got.t, want)
+    # and against torch on the same rounded operands
+    cells = buf.float().cpu().view(n, Hp, 2 * Wq, 4)[:, :, 3:3 + Wp, :3].permute(0, 3, 1, 2)
+    ref = F.max_pool2d(_round(F.relu(F.conv2d(cells.double(), wt.double(), b.double(), stride=2, padding=3)).float(), dt), 3, 2, 1)
+    ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    gd = got.t.float().cpu().permute(0, 3, 1, 2)
+    assert bool(((gd - ref).abs() <= 2 * ulp * ref.abs() + 1e-3).all()), float((gd - ref).abs().max())
+
+
 def test_conv_fpn_lateral_plus_nearest_upsample(eng):
     from densepose_torchscript_amd.engine import Act
     from densepose_torchscript_amd.pack import conv_from_oihw
