@@ -118,5 +118,9 @@ __device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
                                             Elem<T>::pack2(v[6], v[7]));
 }
 
+// dp_conv_ws.hip: the weight-stationary 3x3 128 -> 128 kernel behind dp_conv2d_nhwc (kernel class 6)
+bool dp_conv_ws128_ok(const dp_conv_params* p);
+int dp_conv_ws128_launch(const dp_conv_params* p, dp_stream_t stream);
+
 static inline hipStream_t as_stream(dp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -98,7 +98,8 @@ typedef struct {
 } dp_conv_params;
 int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
 /* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile,
- * 3 = 128x128 LDS-ring tile, 4 = 256x128 two-workgroup ring tile, 5 = streaming 1x1 (resident weights) - profiling / roofline bookkeeping only */
+ * 3 = 128x128 LDS-ring tile, 4 = 256x128 two-workgroup ring tile, 5 = streaming 1x1 (resident weights), 6 = weight-stationary 3x3
+ * 128 -> 128 (weights in registers) - profiling / roofline bookkeeping only */
 int dp_conv2d_kernel_class(const dp_conv_params* p);
 /* pixel rows of the tile dp_conv2d_nhwc will use for these parameters (the 256-cout ring kernel picks 128 .. 256 rows in
  * steps of 32 to fit the launch into whole rounds of the chip) - profiling / roofline bookkeeping only */

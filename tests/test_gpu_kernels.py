@@ -435,6 +435,42 @@ def test_stem_pool_fused_equals_conv_then_pool(eng, dt, shape):
     assert bool(((gd - ref).abs() <= 2 * ulp * ref.abs() + 1e-3).all()), float((gd - ref).abs().max())
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(1, 50, 84, True), (2, 37, 45, True), (3, 33, 32, False), (1, 100, 168, True), (2, 64, 35, False), (1, 47, 130, True)])
+def test_conv3x3_weight_stationary_equals_ring_kernel(eng, dt, shape, monkeypatch):
+    """The weight-stationary 3x3 128 -> 128 kernel (res3 conv2, resnet.py:195-197; weights in registers, pixel rows in an LDS ring)
+    against the LDS-ring kernel it replaces - bit-identical (same K order) - and torch in fp64. Odd heights (a last single
+    row), widths that are no multiple of the 16-pixel strip, several images."""
+    from densepose_torchscript_amd import lib as L
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    e = eng[dt]
+    N, H, W, relu = shape
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W)
+    x = _round(torch.randn((N, 128, H, W), generator=g), dt)
+    w = _round(torch.randn((128, 128, 3, 3), generator=g) * (1.0 / 1152) ** 0.5, dt)
+    b = torch.randn((128,), generator=g) * 0.3
+    layer = conv_from_oihw("conv2", w.numpy(), b.numpy(), 128, 1, 1, 1, e.dt, e.device)
+    xa = Act(_nhwc(x, 128, e.tdt, e.device), N, H, W, 128)
+    p = L.ConvParams()
+    p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, 128, H, W, 128, 128, 1152
+    p.stride, p.ntaps, p.dtype, p.hi_off, p.wi_off = 1, 9, e.dt, -1, -1
+    p.osN, p.osH, p.osW = H * W * 128, W * 128, 128
+    p.out = 1
+    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 6
+    got = e.conv(layer, xa, relu=relu)
+    monkeypatch.setenv("DP_CONV_WS", "0")
+    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) != 6
+    want = e.conv(layer, xa, relu=relu)
+    torch.cuda.synchronize()
+    assert torch.equal(got.t, want.t)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = F.relu(ref) if relu else ref
+    ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    gd = got.t.float().cpu().permute(0, 3, 1, 2).double()
+    assert bool(((gd - ref).abs() <= ulp * ref.abs() + 2e-3).all()), float((gd - ref).abs().max())
+
+
 def test_conv_fpn_lateral_plus_nearest_upsample(eng):
     from densepose_torchscript_amd.engine import Act
     from densepose_torchscript_amd.pack import conv_from_oihw
