@@ -762,31 +762,33 @@ static int num_cus();
 //     after their last use, so the next tile's loads fly during the current tile's MFMAs, epilogue and stores.
 // Wave tile = 16 cout tiles x 2 pixel tiles = 128 accumulator registers; one workgroup (4 waves) per CU.
 // =====================================================================================================
-template <typename T, int KP>
+// NB = 64-cout blocks per workgroup slice: 4 (256 couts; K up to 8 planes = 128 KiB of weights) or 2 (128 couts; K up to 16
+// planes: the 512 -> 128 conv1 layers of res3).
+template <typename T, int KP, int NB>
 __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const ConvArgs p) {
   static_assert(sizeof(T) == 2, "16-bit storage only (fp32 parity mode stays on the generic kernels)");
   constexpr int TP = 2;                 // 32 pixels per wave tile
-  constexpr int NB = 4;                 // 64-cout blocks per wave (256 couts)
-  constexpr int W_PLANE = 256 * 64;     // bytes of one K plane of the weight slice
+  constexpr int NC = NB * 64;           // couts of the slice
+  constexpr int W_PLANE = NC * 64;      // bytes of one K plane of the weight slice
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const bias_s = reinterpret_cast<float*>(smem + KP * W_PLANE);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n0 = blockIdx.y * 256;
+  const int n0 = blockIdx.y * NC;
 
   // ---- weights of this cout slice -> LDS, once: piece = (plane kp, 16-row group rg), 1 KiB per wave-instruction
   {
     const int srow = lane >> 2;
     const int scc = (lane & 3) ^ swz(srow);
     const T* __restrict__ wbase = reinterpret_cast<const T*>(p.weight) + (long long)(n0 + srow) * p.Kpad + scc * 8;
-    for (int piece = wave; piece < KP * 16; piece += 4) {
-      const int kp = piece >> 4, rg = piece & 15;
+    for (int piece = wave; piece < KP * (NC / 16); piece += 4) {
+      const int kp = piece / (NC / 16), rg = piece % (NC / 16);
       const T* src = wbase + (long long)(rg * 16) * p.Kpad + kp * 32;
       __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(src), DP_LDS_PTR(smem + kp * W_PLANE + rg * 1024), 16, 0, 0);
     }
-    bias_s[tid] = p.bias[n0 + tid];
+    if (tid < NC) bias_s[tid] = p.bias[n0 + tid];
   }
   __syncthreads();  // (vmcnt(0) + barrier)
 
@@ -906,22 +908,23 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const ConvArgs p
   }
 }
 
-template <typename T, int KP>
+template <typename T, int KP, int NB = 4>
 int launch_conv_stream(const ConvArgs& a, hipStream_t stream) {
   if constexpr (sizeof(T) != 2) {
     return dp_fail(DP_ERR_UNSUPPORTED, "conv1x1_stream_kernel: 16-bit storage only");
   } else {
-    constexpr int lds = KP * 256 * 64 + 256 * 4;
+    constexpr int NC = NB * 64;
+    constexpr int lds = KP * NC * 64 + NC * 4;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel<T, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel<T, KP, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_set = true;
     }
-    const int slices = a.Cout / 256;
+    const int slices = a.Cout / NC;
     const int n_wt = (a.M + 31) / 32;
     int gx = (num_cus() + slices - 1) / slices;   // one workgroup per CU over all slices
     if (gx > (n_wt + 3) / 4) gx = (n_wt + 3) / 4;
-    hipLaunchKernelGGL((conv1x1_stream_kernel<T, KP>), dim3(gx, slices), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv1x1_stream_kernel<T, KP, NB>), dim3(gx, slices), dim3(256), lds, stream, a);
     return dp_check_launch("conv1x1_stream_kernel");
   }
 }
@@ -960,8 +963,11 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   // ... or the FPN top-down map read through a nearest x2 up-sampling (rshift 1, a plain NHWC tensor of half the size)
   const bool up_res = p->residual && p->rshift == 1 && p->Ho % 2 == 0 && p->Wo % 2 == 0 && p->rsH == (long long)(p->Wo / 2) * p->rsW &&
                       p->rsN == (long long)(p->Ho / 2) * p->rsH && (long long)(p->N + 2) * p->rsN * 2 < (1ll << 31);
+  // slice shapes: 256 couts with K = 2 / 4 / 8 planes of 64 B, or exactly 128 couts with K = 16 planes (the 512 -> 128 conv1 of res3)
+  const bool stream_shape = ((kb == 128 || kb == 256 || kb == 512) && p->Cout % 256 == 0 && p->Cout_w % 256 == 0) ||
+                            (kb == 1024 && p->Cout == 128 && p->Cout_w == 128);
   const bool stream_ok = es == 2 && p->ntaps == 1 && p->stride == 1 && (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == 0 && p->wi_off == 0 && p->H == p->Ho && p->W == p->Wo &&
-                         (kb == 128 || kb == 256 || kb == 512) && p->Kpad == p->Cin && p->Cout % 256 == 0 && p->Cout_w % 256 == 0 &&
+                         stream_shape && p->Kpad == p->Cin &&
                          !p->out_f32 && lin_out && (lin_res || up_res) && M >= 4096 &&
                          // 32-bit buffer offsets, rows up to one grid stride of tiles past the end are addressed
                          (M + (1ll << 16)) * 2 * (p->Cin > p->osW ? p->Cin : (p->osW > p->rsW ? p->osW : p->rsW)) < (1ll << 31);
@@ -1112,6 +1118,7 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
     a.tiles_n = p->Cout / 256;
     a.n_tiles = 0;
     const int kp = p->Cin * es / 64;
+    if (kp == 16) { DP_BY_DTYPE((launch_conv_stream<T, 16, 2>(a, s))); }
     if (kp == 2) { DP_BY_DTYPE((launch_conv_stream<T, 2>(a, s))); }
     if (kp == 4) { DP_BY_DTYPE((launch_conv_stream<T, 4>(a, s))); }
     DP_BY_DTYPE((launch_conv_stream<T, 8>(a, s)));

@@ -111,6 +111,7 @@ STREAM_CASES = [
     (1, 128, 70, 61, 512, 1, 1, 0, 1, True, True),     # res3 conv3: two cout slices
     (1, 256, 65, 64, 256, 1, 1, 0, 1, False, False),   # decoder predictor
     (1, 256, 66, 63, 1024, 1, 1, 0, 1, True, True),    # res4 conv3: four cout slices
+    (2, 512, 50, 47, 128, 1, 1, 0, 1, True, False),    # res3 conv1: 128 couts, K = 16 planes (the NB = 2 instance)
 ]
 
 
