@@ -325,6 +325,13 @@ def main():
         roofline["ring256_family"] = {"tflops": round(ff / ft / 1e12, 2), "frac": round(ff / ft / peak, 4), "calls_per_step": fc // args.steps,
                                       "ms_per_step": round(1e3 * ft / args.steps, 3)}
 
+    # ... and so is the weight-stationary 3x3 kernel (instances per channel count and ReLU flag)
+    fam = [v for c, v in agg.items() if c.startswith("conv3x3_wsr_kernel<")]
+    if fam:
+        ff, ft, fc = sum(v[0] for v in fam), sum(v[1] for v in fam), sum(v[2] for v in fam)
+        roofline["wsr_family"] = {"tflops": round(ff / ft / 1e12, 2), "frac": round(ff / ft / peak, 4), "calls_per_step": fc // args.steps,
+                                  "ms_per_step": round(1e3 * ft / args.steps, 3)}
+
     result = None
     if rank == 0:
         images = args.batch * world * args.steps

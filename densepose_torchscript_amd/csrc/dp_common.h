@@ -36,10 +36,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) { return __builtin_bit_cast(float, lo16 << 16); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-  // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
-  bf16_t ha = (bf16_t)a, hb = (bf16_t)b;
-  return (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
+  // a vector conversion: hipcc emits ONE v_cvt_pk_bf16_f32 for the pair (RNE, NaN stays NaN); two scalar casts cost
+  // two of them plus a shift and an or
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 __device__ __forceinline__ float f16_bits_to_f32(uint32_t lo16) { return (float)__builtin_bit_cast(f16_t, (uint16_t)lo16); }
 __device__ __forceinline__ uint32_t pack_f16x2(float a, float b) {
@@ -118,9 +121,9 @@ __device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
                                             Elem<T>::pack2(v[6], v[7]));
 }
 
-// dp_conv_ws.hip: the weight-stationary 3x3 128 -> 128 kernel behind dp_conv2d_nhwc (kernel class 6)
-bool dp_conv_ws128_ok(const dp_conv_params* p);
-int dp_conv_ws128_launch(const dp_conv_params* p, dp_stream_t stream);
+// dp_conv_ws.hip: the weight-stationary 3x3 kernel (128 -> 128 and 256 -> 256 channels) behind dp_conv2d_nhwc (kernel class 6)
+bool dp_conv_wsr_ok(const dp_conv_params* p);
+int dp_conv_wsr_launch(const dp_conv_params* p, dp_stream_t stream);
 
 static inline hipStream_t as_stream(dp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,189 +1,14 @@
-// Weight-stationary 3x3 convolution, 128 -> 128 channels (the conv2 layers of res3,
-// /root/reference/detectron2/modeling/backbone/resnet.py:195-197), 16-bit storage.
-//
-// On the LDS-ring kernels this layer runs at 0.22 of the MFMA peak: per 64-byte K plane a workgroup re-stages 128 weight rows
-// and its pixel rows, waits, synchronises - 36 plane steps whose cost is latency, not arithmetic. But the
-// whole 128 x 1152 weight matrix is only 288 KiB: it fits the REGISTER FILE of one CU (512 KiB). So here nothing about the
-// weights ever moves after the prologue:
-//   * wave w of a workgroup (8 waves, one workgroup per CU) owns output channels 16w .. 16w + 15 and keeps their 36 K-step
-//     fragments (144 VGPRs) for the whole launch;
-//   * the workgroup walks down a 16-pixel-wide column strip, RP = 2 output rows per step. The input rows it needs (r - 1 .. r + RP,
-//     18 pixels x 256 B each: the strip plus a halo pixel each side) live in an LDS ring, filled one step ahead with
-//     whole-line loads; zero padding is decided at the load (out-of-range buffer offsets return 0);
-//   * every wave reads the same B fragments from LDS (48 per step: 4 input rows x 3 column taps x 4 channel blocks; the fragment
-//     of input row q feeds output row t with kernel row q - t) and runs 72 MFMAs on them: no barrier, no global traffic, no
-//     weight traffic inside a step;
-//   * the 16-channel slices of the 8 waves are assembled into whole 256-byte pixel rows in an LDS buffer and stored as
-//     whole lines. Two barriers per step. (RP = 4 halves the barriers per row and measured 5 % SLOWER: the step is not
-//     barrier-bound.)
-// K order per output pixel is the packed one (channel block major, taps inner), so results are bit-identical to the ring kernel.
+// Weight-stationary 3x3 convolutions (16-bit storage): the weights of a cout slice live in the REGISTER FILE of a CU for the
+// whole launch, input rows stream through an LDS ring. Behind dp_conv2d_nhwc (dp_conv.hip, kernel class 6).
 #include "dp_common.h"
 #include "dp_mma.h"
 #include <stdlib.h>
 
-namespace {
-
-constexpr int kWsPx = 18;                    // staged pixels per input row: 16 + one halo pixel each side
-constexpr int kWsRow = kWsPx * 256;          // bytes
-#ifndef DP_WS_RP
-#define DP_WS_RP 2
-#endif
 #ifndef DP_EXP
-#define DP_EXP 0
+#define DP_EXP 0      // diagnostic builds: 1 no fragment reads, 4 no MFMAs, 8 no row fetches, 16 in-kernel phase stamps
 #endif
-constexpr int kWsRP = DP_WS_RP;              // output rows per step
-constexpr int kWsSlots = kWsRP <= 2 ? 8 : 16; // ring slots >= RP + 2 rows in use + RP being prefetched
-constexpr int kWsOut = kWsRP * 16 * 256;     // RP output rows x 16 pixels x 128 channels
-constexpr int kWsLds = kWsSlots * kWsRow + kWsOut;   // 90,112 B
-constexpr int kWsRowItems = kWsPx * 16;      // 16-byte items of one staged row
 
-struct WsArgs {
-  const void* in;
-  const void* w;
-  const float* bias;
-  void* out;
-  int N, H, W, relu, kpad;
-  int n_strips, n_seg, seg_rows, n_jobs;
-  unsigned bytes;     // extent of in / out
-};
-
-// chunk c (16 B) of pixel p of a row buffer; any 16 consecutive pixels at one chunk index hit 16 different 16-byte slots
-__device__ __forceinline__ int ws_addr(int p, int c) { return p * 256 + ((c ^ (p & 15)) << 4); }
-
-template <typename T>
-__global__ __launch_bounds__(512, 2) void conv3x3_ws128_kernel(const WsArgs p) {
-  static_assert(sizeof(T) == 2, "16-bit storage only");
-  constexpr int RP = kWsRP;
-  constexpr int NF = 4 * (RP + 2) * 3;       // fragments per step: channel block x input row x column tap
-  constexpr int PRE = (RP * kWsRowItems + 511) / 512;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const ring = smem;
-  unsigned char* const obuf = smem + kWsSlots * kWsRow;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = lane & 15, fq = lane >> 4;
-
-  // ---- this wave's 16 output channels x K = 1152, in registers for the whole launch
-  u32x4 wfr[36];
-  {
-    const T* __restrict__ w = reinterpret_cast<const T*>(p.w) + (long long)(wave * 16 + fr) * p.kpad + fq * 8;
-#pragma unroll
-    for (int s = 0; s < 36; ++s) wfr[s] = *reinterpret_cast<const u32x4*>(w + s * 32);
-  }
-  // physical weight row 16 w + 4 fq + e carries logical channel c_l + e (pack.py row permutation inside every 64-cout block)
-  const int wi = wave & 3;
-  const int c_l = (wave >> 2) * 64 + (wi >> 1) * 32 + fq * 8 + (wi & 1) * 4;
-  const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + c_l);
-  const int gran = c_l >> 2;     // 8-byte granule of the pixel's 256 bytes this lane produces
-
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.bytes, 0x00020000);
-  constexpr int OOB = (int)0x80000000;
-
-  // Work = steps (RP output rows of one 16-pixel column strip of one image), numbered column strip by column strip, top to
-  // bottom. Workgroup g takes the contiguous range [g S / G, (g + 1) S / G): every CU gets the same number of steps (+- 1) and
-  // at most two (re)starts of the row ring - no job queue, no imbalance from unequal job counts.
-  const int steps_per_col = (p.H + RP - 1) / RP;
-  const long long S = (long long)p.N * p.n_strips * steps_per_col;
-  const int s_begin = (int)(S * blockIdx.x / gridDim.x), s_end = (int)(S * (blockIdx.x + 1) / gridDim.x);
-  for (int sidx = s_begin; sidx < s_end;) {
-    const int colid = sidx / steps_per_col;
-    const int k0 = sidx - colid * steps_per_col;
-    const int k1 = min(steps_per_col, k0 + (s_end - sidx));      // steps of this column this workgroup owns: k0 .. k1 - 1
-    const int strip = colid % p.n_strips;
-    const int n = colid / p.n_strips;
-    const int r0 = k0 * RP;
-    const int r1 = min(k1 * RP, p.H);
-    const int c0 = strip * 16;
-    sidx += k1 - k0;
-
-    auto slot = [&](int row) __attribute__((always_inline)) -> int { return ((row + kWsSlots) & (kWsSlots - 1)) * kWsRow; };
-    // item `it` of a row fill: staged pixel px (image column c0 - 1 + px), 16-byte chunk c
-    auto row_off = [&](int row, int it) __attribute__((always_inline)) -> int {
-      const int px = it >> 4, c = it & 15, col = c0 - 1 + px;
-      return ((unsigned)row < (unsigned)p.H && (unsigned)col < (unsigned)p.W) ? ((n * p.H + row) * p.W + col) * 256 + c * 16 : OOB;
-    };
-
-    __syncthreads();      // the previous column is done with the ring
-    for (int idx = tid; idx < (RP + 2) * kWsRowItems; idx += 512) {   // rows r0 - 1 .. r0 + RP
-      const int q = idx / kWsRowItems, it = idx - q * kWsRowItems;
-      const int row = r0 - 1 + q;
-      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, row_off(row, it), 0, 0);
-      *reinterpret_cast<u32x4*>(ring + slot(row) + ws_addr(it >> 4, it & 15)) = v;
-    }
-    __syncthreads();
-
-    for (int r = r0; r < r1; r += RP) {
-      // rows r + RP + 1 .. r + 2 RP (the next step's new rows): fetched now, written to the ring after this step's MFMAs
-      u32x4 pre[PRE];
-      int pre_dst[PRE];
-      const bool more = r + RP < r1;
-#pragma unroll
-      for (int k = 0; k < PRE; ++k) {
-        const int idx = tid + k * 512;
-        const int q = idx / kWsRowItems, it = idx - q * kWsRowItems;
-        const int row = r + RP + 1 + q;
-        const bool in_range = idx < RP * kWsRowItems && more;
-        pre[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (in_range && row <= r1) ? row_off(row, it) : OOB, 0, 0);
-        pre_dst[k] = in_range ? slot(row) + ws_addr(it >> 4, it & 15) : -1;
-      }
-
-      f32x4 acc[RP];      // output rows r .. r + RP - 1
-#pragma unroll
-      for (int t = 0; t < RP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // fragment f = (channel block cb, input row q, column tap dx): input row r - 1 + q feeds output row r + t with kernel row q - t
-      auto frag = [&](int f) __attribute__((always_inline)) -> u32x4 {
-        const int cb = f / (3 * (RP + 2)), q = (f % (3 * (RP + 2))) / 3, dx = f % 3;
-        return *reinterpret_cast<const u32x4*>(ring + slot(r - 1 + q) + ws_addr(fr + dx, cb * 4 + fq));
-      };
-      constexpr int AHEAD = 4;              // fragments in flight ahead of their MFMAs (8 waves share the LDS)
-      u32x4 bf[AHEAD + 1];
-#pragma unroll
-      for (int f = 0; f < AHEAD; ++f) bf[f] = frag(f);
-      static_for<0, NF>([&](auto ff) {
-        constexpr int f = decltype(ff)::value;
-        constexpr int cb = f / (3 * (RP + 2)), q = (f % (3 * (RP + 2))) / 3, dx = f % 3;
-        if constexpr (f + AHEAD < NF && !((DP_EXP & 1) && f >= 1)) bf[(f + AHEAD) % (AHEAD + 1)] = frag(f + AHEAD);
-        static_for<0, RP>([&](auto tt) {
-          constexpr int t = decltype(tt)::value;
-          if constexpr (q - t >= 0 && q - t <= 2) Mma<T>::run(wfr[cb * 9 + (q - t) * 3 + dx], bf[f % (AHEAD + 1)], acc[t]);
-        });
-      });
-
-      // ---- epilogue: 4 channels of pixel fr of each output row per lane -> 8-byte granules of the output buffer
-#pragma unroll
-      for (int t = 0; t < RP; ++t) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[t][e] + bias[e];
-          if (p.relu) v[e] = fmaxf(v[e], 0.f);
-        }
-        const int P = t * 16 + fr;
-        uint2 pk = make_uint2(Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3]));
-        *reinterpret_cast<uint2*>(obuf + P * 256 + (((gran >> 1) ^ (P & 15)) << 4) + (gran & 1) * 8) = pk;
-      }
-      if (DP_EXP & 2) continue;
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < (RP * 256 + 511) / 512; ++k) {   // whole lines out: item = (pixel P of the RP x 16 block, chunk c)
-        const int idx = tid + k * 512;
-        const int P = (idx >> 4) & (RP * 16 - 1), c = idx & 15;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(obuf + ws_addr(P, c));
-        const int row = r + (P >> 4), col = c0 + (P & 15);
-        const bool ok = idx < RP * 256 && row < r1 && col < p.W;
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, ok ? ((n * p.H + row) * p.W + col) * 256 + c * 16 : OOB, 0, 0);
-      }
-#pragma unroll
-      for (int k = 0; k < PRE; ++k)
-        if (pre_dst[k] >= 0) *reinterpret_cast<u32x4*>(ring + pre_dst[k]) = pre[k];
-      __syncthreads();
-    }
-  }
-}
-
+namespace {
 int ws_num_cus() {
   int dev = 0;
   hipDeviceProp_t prop;
@@ -191,44 +16,426 @@ int ws_num_cus() {
     return prop.multiProcessorCount;
   return 256;
 }
+}  // namespace
 
-template <typename T>
-int launch_ws(WsArgs a, hipStream_t stream) {
+// =====================================================================================================
+// C -> C channels, 3x3, pad 1, stride 1, for C = 128 (res3 conv2) and C = 256 (res4 conv2, the FPN output convolutions and the
+// decoder's 3x3 convolutions; /root/reference/detectron2/modeling/backbone/resnet.py:195-197, fpn.py:134-135,
+// densepose/modeling/roi_heads/roi_head.py decoder scale heads).
+//
+// On the LDS-ring kernels these layers re-stage 128 - 256 weight rows and their pixel rows per 64-byte K plane, wait, synchronise:
+// 36 - 72 plane steps whose cost is latency, not arithmetic. But a 16-cout x 1152-K slice of the weights is
+// 144 VGPRs of a wave, so here nothing about the weights ever moves after the prologue.
+//
+// Every wave keeps 16 output channels x 1152 K values (36 K steps, 144 VGPRs) for the whole launch. With C = 128 that is the
+// whole K axis (8 waves = 128 couts per workgroup); with C = 256 two waves share a cout group: wave h = 0 contracts channel
+// blocks 0..3, hands its accumulators to wave h = 1 (through LDS) which continues with blocks 4..7 - the K order of the packed
+// matrix, so the result is bit-identical to the ring kernels. The chain is pipelined: in iteration i wave h works on step i - h.
+// A workgroup then covers 64 couts and the grid is (cout slice) x (pixel group); the slices of one pixel group sit on one XCD.
+//   * work = steps (RP output rows of a 16-pixel column strip), numbered strip by strip, top to bottom; a workgroup owns a
+//     contiguous range and NEVER drains between columns: ring rows are addressed by a virtual row number that advances by RP
+//     per step and by 2 more at a column start (the new column's first two rows are fresh);
+//   * input rows travel global -> LDS by LDS-DMA (whole lines, one step ahead, no registers, no ds_write); pixel p's 16-byte
+//     chunk c sits at slot c ^ (2p & 15): fragment reads at any column tap are bank-conflict free (c ^ (p & 15), the first
+//     form's swizzle, costs two LDS cycles per lane group on the centre tap);
+//   * the weight rows are read un-permuted (A row r of wave group g = logical cout 16 g + r), so the four lanes of a pixel
+//     hold 16 consecutive output channels and the epilogue stores 8 bytes per lane straight from the accumulators: no output
+//     staging buffer, ONE barrier per step.
+// =====================================================================================================
+namespace {
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct WsrArgs {
+  const void* in;
+  const void* w;
+  const float* bias;
+  void* out;
+  int N, H, W, relu, kpad, cout;
+  int n_strips, spc, n_slices, n_pg;
+  int S;                       // steps per cout slice
+  unsigned in_bytes, out_bytes;
+  unsigned long long* dbg;     // diagnostic builds (-DDP_EXP=16): per-wave phase cycle sums
+};
+
+template <int N>
+__device__ __forceinline__ void wsr_wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+// step bookkeeping without divisions: a step's image, first column, first output row and the ring row (virtual row modulo the
+// ring size) of its input row r - 1; `first` = none of its input rows is in the ring yet
+struct WsrStep {
+  int n, c0, r, um, first;
+};
+
+template <typename T, int C, int RP, bool RELU>
+__global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  static_assert(C == 128 || C == 256, "channel counts the register budget covers");
+  constexpr int KS = C / 128;                 // K parts = waves chained through the accumulator
+  constexpr int NG = 8 / KS;                  // cout groups (16 couts) per workgroup
+  constexpr int CS = NG * 16;                 // couts per workgroup
+  constexpr int PIX = 2 * C;                  // bytes per pixel in global memory
+  constexpr int PP = PIX + 32;                // ... and in the ring: the 32-byte pad makes pixel p's chunk c land on 16-byte
+                                              // slot (2p + c) mod 16 - fragment reads at every column tap are conflict free and
+                                              // the address stays affine (column tap and channel block are instruction offsets)
+  constexpr int PPR = (18 * PP + 1023) / 1024;   // DMA pieces per ring row
+  constexpr int ROWB = PPR * 1024;
+  constexpr int NQ = RP + 2;                  // input rows of a step
+  constexpr int NSLOT = (KS + 1) * RP + 4;    // rows of KS steps in use + RP being fetched + 2 + 2 more at a column start
+  constexpr int NF = 4 * NQ * 3;              // fragments per step and wave: channel block x input row x column tap
+  constexpr int HAND = NSLOT * ROWB;          // accumulator hand-over buffers [group][link][parity][row][lane]
+  constexpr int OOB = (int)0x80000000;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  // cout group and K part. Waves w and w + 4 share a SIMD and the older one (w < 4) wins the matrix pipe whenever both are
+  // ready. With two K parts the older wave takes part 1: it first fetches the handed-over accumulators and stores the previous
+  // step's outputs while its partner (part 0: nothing to wait for) already runs MFMAs, then runs a loop of nothing but reads and
+  // MFMAs; the younger wave issues the row fetches early in ITS loop - under the older wave's MFMAs - and hands its sums over.
+  const int g = wave % NG, h = KS == 1 ? 0 : 1 - wave / NG;
+  const int b = blockIdx.x;
+  const int slice = (b >> 3) % p.n_slices;
+  const int pg = (b & 7) + 8 * (b / (8 * p.n_slices));
+
+  const int s_begin = (int)((long long)p.S * pg / p.n_pg), s_end = (int)((long long)p.S * (pg + 1) / p.n_pg);
+  const int nst = s_end - s_begin;
+  if (nst <= 0) return;
+
+  // ---- this wave's 16 couts x its K part, in registers for the whole launch (A row fr = logical cout cbase + fr)
+  const int cbase = slice * CS + g * 16;
+  u32x4 wfr[36];
+  {
+    const int L = cbase + fr, l64 = L & 63;
+    const int rem = l64 & 31;
+    const int phys = (L & ~63) + (((l64 >> 5) * 2 + ((rem >> 2) & 1)) * 16) + (rem >> 3) * 4 + (rem & 3);   // pack.py's row permutation
+    const T* __restrict__ w = reinterpret_cast<const T*>(p.w) + (long long)phys * p.kpad + h * 1152 + fq * 8;
+#pragma unroll
+    for (int s = 0; s < 36; ++s) wfr[s] = *reinterpret_cast<const u32x4*>(w + s * 32);
+  }
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + cbase + fq * 4);
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+
+  const int frag_lane = fr * PP + fq * 16 + h * 256;     // lane part of a fragment address: pixel fr, chunk h * 16 + fq
+  const int n_cols = p.n_strips * 16;
+
+  auto advance = [&](WsrStep& st) __attribute__((always_inline)) {
+    st.r += RP; st.um += RP; st.first = 0;
+    if (st.r >= p.H) {
+      st.r = 0; st.um += 2; st.first = 1; st.c0 += 16;
+      if (st.c0 >= n_cols) { st.c0 = 0; st.n += 1; }
+    }
+    if (st.um >= NSLOT) st.um -= NSLOT;
+  };
+  // Fetching the rows of a step that are not in the ring yet: whole 1 KiB pieces of ring rows; the lanes that fall on a pixel's
+  // pad or outside the image read zeros (out-of-range buffer offset). In the steady state (RP new rows) piece j of this wave is
+  // always the same (row, piece-in-row), so its per-lane part is computed once: staged pixel and byte offset inside the row.
+  // With two K parts the part-0 waves issue every fetch (spread over their MFMA loop) and the part-1 waves every store.
+  constexpr int ND = KS == 1 ? 8 : NG;         // fetching waves
+  constexpr int NJ = (RP * PPR + ND - 1) / ND; // pieces per fetching wave and step
+  const bool dma_wave = h == 0;
+  const int dw = KS == 1 ? wave : g;           // index among the fetching waves
+  int dj_px[NJ], dj_off[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int pc = dw + ND * j, pr = pc % PPR;
+    const int o = pr * 1024 + lane * 16;
+    const int px = o / PP, wb = o - px * PP;
+    const bool lane_ok = px < 18 && wb < PIX;
+    dj_px[j] = lane_ok ? px : 0x10000;
+    dj_off[j] = px * PIX + wb;
+  }
+  // piece j of the steady-state fetch of step st (is_lo / is_hi / is_base: issue_setup)
+  int is_lo = 0, is_hi = 0, is_base = 0;
+  auto issue_setup = [&](const WsrStep& st) __attribute__((always_inline)) {
+    is_lo = st.c0 == 0 ? 1 : 0;                        // staged pixel 0 is column c0 - 1
+    is_hi = min(17, p.W - st.c0);                      // column c0 - 1 + px < W
+    is_base = ((st.n * p.H + st.r + 1) * p.W + st.c0 - 1) * PIX;    // input row q = 2 (image row r + 1)
+  };
+  auto issue_piece = [&](const WsrStep& st, auto jj) __attribute__((always_inline)) {
+    constexpr int j = decltype(jj)::value;
+    const int pc = dw + ND * j;
+    if (pc < RP * PPR) {
+      const int qq = pc / PPR, pr = pc - qq * PPR;
+      const int cnt = (unsigned)(st.r + 1 + qq) < (unsigned)p.H ? is_hi - is_lo + 1 : 0;
+      const bool ok = (unsigned)(dj_px[j] - is_lo) < (unsigned)cnt;
+      const int off = ok ? is_base + qq * (p.W * PIX) + dj_off[j] : OOB;
+      int slot = st.um + 2 + qq;
+      if (slot >= NSLOT) slot -= NSLOT;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(smem + slot * ROWB + pr * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  // ... and the general form (all NQ rows: the first step of a workgroup and of every column)
+  auto issue_all_rows = [&](const WsrStep& st) __attribute__((always_inline)) {
+    for (int pc = wave; pc < NQ * PPR; pc += 8) {
+      const int q = pc / PPR, pr = pc - q * PPR;
+      const int o = pr * 1024 + lane * 16;
+      const int px = o / PP, wb = o - px * PP;
+      const int row = st.r - 1 + q, col = st.c0 - 1 + px;
+      const bool ok = px < 18 && wb < PIX && (unsigned)row < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
+      const int off = ok ? ((st.n * p.H + row) * p.W + col) * PIX + wb : OOB;
+      int slot = st.um + q;
+      if (slot >= NSLOT) slot -= NSLOT;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(smem + slot * ROWB + pr * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  // step states: st_i = the step whose rows are fetched this iteration (i + 1), st_w[h] = the step wave part h computes (i - h)
+  WsrStep st_i, st_w[KS];
+  {
+    const int colid = s_begin / p.spc, k = s_begin - colid * p.spc;
+    st_i.n = colid / p.n_strips;
+    st_i.c0 = (colid - st_i.n * p.n_strips) * 16;
+    st_i.r = k * RP;
+    st_i.um = 0;
+    st_i.first = 1;
+  }
+  issue_all_rows(st_i);
+#pragma unroll
+  for (int k = 0; k < KS; ++k) st_w[k] = st_i;
+  advance(st_i);
+  wsr_wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+
+  // The epilogue of a step is deferred into the NEXT step's MFMA loop (its accumulators, output offset and row count wait
+  // in registers): the two waves of a SIMD run the same program in lockstep, so a phase without MFMAs idles the matrix pipe
+  // for both. For the same reason the steady-state row fetch is issued piece by piece between the MFMAs.
+  f32x4 eacc[RP];
+  int e_off = 0, e_rows = 0, e_col = 0;
+  bool have_prev = false;
+  const int opix = p.cout * 2;
+  auto epi_row = [&](auto tt) __attribute__((always_inline)) {
+    constexpr int t = decltype(tt)::value;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = eacc[t][e] + bias[e];
+      if constexpr (RELU) v[e] = fmaxf(v[e], 0.f);
+    }
+    const bool ok = t < e_rows && e_col < p.W;
+    const u32x2 pk = {Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3])};
+    __builtin_amdgcn_raw_buffer_store_b64(pk, rs_out, ok ? e_off + t * (p.W * opix) : OOB, 0, 0);
+  };
+
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+#define DP_STAMP(k) if constexpr (DP_EXP & 16) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - tl; tl = t_; }
+  unsigned long long tl = (DP_EXP & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  for (int i = 0; i < nst + KS - 1; ++i) {
+    const bool fetch = i + 1 < nst && !(DP_EXP & 8);
+    const bool fetch_inl = fetch && !st_i.first;
+    const bool fetch_all = fetch && st_i.first;
+    if (fetch_all) issue_all_rows(st_i);       // every wave takes part
+    if (fetch_inl) issue_setup(st_i);
+    asm volatile("" ::: "memory");
+    DP_STAMP(0)
+    const int sw = i - h;
+    const bool had_prev = have_prev;
+    if (sw >= 0 && sw < nst) {
+      WsrStep st = st_w[0];
+      if constexpr (KS > 1) { if (h == 1) st = st_w[1]; }
+      int va[NQ];       // per input row: ring row base + lane part
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        int slot = st.um + q;
+        if (slot >= NSLOT) slot -= NSLOT;
+        va[q] = slot * ROWB + frag_lane;
+      }
+
+      f32x4 acc[RP];
+      const bool fetch_here = fetch_inl && dma_wave;
+      if constexpr (KS > 1) {
+        if (h > 0) {
+          const unsigned char* hb = smem + HAND + (((g * (KS - 1) + h - 1) * 2 + ((i - 1) & 1)) * RP) * 1024 + lane * 16;
+#pragma unroll
+          for (int t = 0; t < RP; ++t) acc[t] = *reinterpret_cast<const f32x4*>(hb + t * 1024);
+          if (had_prev) static_for<0, RP>([&](auto tt) { epi_row(tt); });    // under the hand-over's LDS latency
+        } else {
+#pragma unroll
+          for (int t = 0; t < RP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < RP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+
+      // fragment f = (channel block cbl, input row q, column tap dx): input row r - 1 + q feeds output row r + t with kernel row q - t
+      auto frag = [&](auto ff) __attribute__((always_inline)) -> u32x4 {
+        constexpr int f = decltype(ff)::value;
+        constexpr int cbl = f / (3 * NQ), q = (f % (3 * NQ)) / 3, dx = f % 3;
+        return *reinterpret_cast<const u32x4*>(smem + va[q] + (dx * PP + cbl * 64));
+      };
+      constexpr int AHEAD = 6;
+      u32x4 bf[AHEAD + 1];
+      static_for<0, AHEAD>([&](auto ff) { bf[decltype(ff)::value] = frag(ff); });
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, NF>([&](auto ff) {
+        constexpr int f = decltype(ff)::value;
+        constexpr int cbl = f / (3 * NQ), q = (f % (3 * NQ)) / 3, dx = f % 3;
+        // Memory instructions between the MFMAs. One K part: fetch pieces in the first half of the loop, the previous step's
+        // stores in the second, so that "all but the last RP vector-memory operations" at the end of the iteration means
+        // "every fetch". Two K parts: the part-0 waves fetch, early in the loop.
+        if constexpr (KS == 1) {
+          constexpr int DJ = (NF / 2) / NJ, DT = (NF / 2) / RP;
+          if constexpr (f < NJ * DJ && f % DJ == DJ / 2) {
+            if (fetch_inl) issue_piece(st_i, std::integral_constant<int, f / DJ>{});
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr (f >= NF / 2 && f < NF / 2 + RP * DT && (f - NF / 2) % DT == DT / 2) {
+            if (had_prev) epi_row(std::integral_constant<int, (f - NF / 2) / DT>{});
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+          if constexpr (f >= 4 && f < 4 + 2 * NJ && f % 2 == 0) {
+            if (fetch_here) issue_piece(st_i, std::integral_constant<int, (f - 4) / 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // order pinned: the scheduler otherwise sinks every read to one MFMA before its use (lgkmcnt(1) chains)
+        if constexpr (f + AHEAD < NF && !(DP_EXP & 1)) bf[(f + AHEAD) % (AHEAD + 1)] = frag(std::integral_constant<int, (f + AHEAD < NF ? f + AHEAD : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, RP>([&](auto tt) {
+          constexpr int t = decltype(tt)::value;
+          if constexpr (q - t >= 0 && q - t <= 2 && !((DP_EXP & 4) && f >= AHEAD + 1)) Mma<T>::run(wfr[cbl * 9 + (q - t) * 3 + dx], bf[f % (AHEAD + 1)], acc[t]);
+          if constexpr ((DP_EXP & 4) && t == 0 && f >= AHEAD + 1) acc[0][0] += __builtin_bit_cast(float, bf[f % (AHEAD + 1)][0]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      have_prev = false;
+      DP_STAMP(1)
+      if (KS > 1 && h < KS - 1) {
+        unsigned char* hb = smem + HAND + (((g * (KS - 1) + h) * 2 + (i & 1)) * RP) * 1024 + lane * 16;
+#pragma unroll
+        for (int t = 0; t < RP; ++t) *reinterpret_cast<f32x4*>(hb + t * 1024) = acc[t];
+      } else {
+        // 4 consecutive channels of pixel fr of each output row per lane, the four lanes of a pixel 32 contiguous bytes
+#pragma unroll
+        for (int t = 0; t < RP; ++t) eacc[t] = acc[t];
+        e_col = st.c0 + fr;
+        e_off = ((st.n * p.H + st.r) * p.W + e_col) * opix + (cbase + fq * 4) * 2;
+        e_rows = p.H - st.r;
+        have_prev = true;
+      }
+    } else {
+      if (fetch_inl && dma_wave) static_for<0, NJ>([&](auto jj) { issue_piece(st_i, jj); });
+      if (had_prev) static_for<0, RP>([&](auto tt) { epi_row(tt); });
+      have_prev = false;
+    }
+    DP_STAMP(2)
+    // the rows fetched in this iteration have landed (they are older than this iteration's stores; with two K parts a wave
+    // either fetches or stores)
+    if (KS == 1 && had_prev) wsr_wait_vm<RP>();
+    else if (dma_wave) wsr_wait_vm<0>();
+    else if (fetch_all) { if (had_prev) wsr_wait_vm<RP>(); else wsr_wait_vm<0>(); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DP_STAMP(3)
+    __builtin_amdgcn_s_barrier();
+    DP_STAMP(4)
+    if constexpr (KS > 1) st_w[1] = st_w[0];
+    st_w[0] = st_i;
+    advance(st_i);
+  }
+  if (have_prev) static_for<0, RP>([&](auto tt) { epi_row(tt); });
+  if constexpr (DP_EXP & 16) {
+    if (lane == 0 && p.dbg) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) p.dbg[(blockIdx.x * 8 + wave) * 8 + k] = ph[k];
+      p.dbg[(blockIdx.x * 8 + wave) * 8 + 5] = nst;
+    }
+  }
+#undef DP_STAMP
+}
+
+template <typename T, int C, int RP, bool RELU>
+int launch_wsr_r(WsrArgs a, hipStream_t stream) {
+  constexpr int KS = C / 128, NG = 8 / KS, CS = NG * 16;
+  constexpr int ROWB = (18 * (2 * C + 32) + 1023) / 1024 * 1024, NSLOT = (KS + 1) * RP + 4;
+  constexpr int lds = NSLOT * ROWB + (KS > 1 ? NG * (KS - 1) * 2 * RP * 1024 : 0);
+  static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   static int cus = 0;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws128_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, kWsLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wsr_kernel<T, C, RP, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     cus = ws_num_cus();
     attr_set = true;
   }
   a.n_strips = (a.W + 15) / 16;
-  const long long steps = (long long)a.N * a.n_strips * ((a.H + kWsRP - 1) / kWsRP);
-  a.n_seg = a.seg_rows = 0;
-  a.n_jobs = (int)steps;
-  const int gx = steps < cus ? (int)steps : cus;
-  hipLaunchKernelGGL((conv3x3_ws128_kernel<T>), dim3(gx), dim3(512), kWsLds, stream, a);
-  return dp_check_launch("conv3x3_ws128_kernel");
+  a.spc = (a.H + RP - 1) / RP;
+  a.S = a.N * a.n_strips * a.spc;
+  a.n_slices = a.cout / CS;
+  int groups = cus / (8 * a.n_slices);
+  if (groups < 1) groups = 1;
+  a.n_pg = groups * 8;
+  a.dbg = nullptr;
+#if DP_EXP & 16
+  static unsigned long long* dbg = nullptr;
+  const int nblk = a.n_pg * a.n_slices;
+  if (!dbg) (void)hipMalloc(&dbg, sizeof(unsigned long long) * 8 * 8 * 4096);
+  a.dbg = dbg;
+  (void)hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 8 * 8 * nblk, stream);
+#endif
+  hipLaunchKernelGGL((conv3x3_wsr_kernel<T, C, RP, RELU>), dim3(a.n_pg * a.n_slices), dim3(512), lds, stream, a);
+#if DP_EXP & 16
+  {
+    static int shown = 0;
+    if (shown++ == 4) {   // a warm launch
+      (void)hipStreamSynchronize(stream);
+      unsigned long long* hbuf = (unsigned long long*)malloc(sizeof(unsigned long long) * 64 * nblk);
+      (void)hipMemcpy(hbuf, dbg, sizeof(unsigned long long) * 64 * nblk, hipMemcpyDeviceToHost);
+      for (int w = 0; w < 8; ++w) {
+        double sum[5] = {0, 0, 0, 0, 0}, n = 0;
+        for (int b = 0; b < nblk; ++b) { for (int k = 0; k < 5; ++k) sum[k] += (double)hbuf[(b * 8 + w) * 8 + k]; n += (double)hbuf[(b * 8 + w) * 8 + 5]; }
+        fprintf(stderr, "wsr wave %d: per step cycles: issue %.0f  mfma %.0f  epilogue %.0f  vmcnt/lgkm wait %.0f  barrier %.0f  (steps/wg %.1f)\n", w,
+                sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, n / nblk);
+      }
+      free(hbuf);
+    }
+  }
+#endif
+  return dp_check_launch("conv3x3_wsr_kernel");
 }
+
+template <typename T, int C, int RP>
+int launch_wsr(const WsrArgs& a, hipStream_t stream) {
+  return a.relu ? launch_wsr_r<T, C, RP, true>(a, stream) : launch_wsr_r<T, C, RP, false>(a, stream);
+}
+
+constexpr int kWsrRP128 = 4, kWsrRP256 = 3;
 
 }  // namespace
 
-// used by dp_conv2d_nhwc (dp_conv.hip): is this launch the 128 -> 128 3x3 / pad 1 / stride 1 layer the kernel is written for?
-bool dp_conv_ws128_ok(const dp_conv_params* p) {
-  const char* e = getenv("DP_CONV_WS");    // A/B knob: 0 keeps the layer on the ring kernels
+// used by dp_conv2d_nhwc (dp_conv.hip): is this launch one of the C -> C 3x3 / pad 1 / stride 1 layers the kernel is written for?
+bool dp_conv_wsr_ok(const dp_conv_params* p) {
+  const char* e = getenv("DP_CONV_WS");    // A/B knob: 0 keeps these layers on the ring kernels
   if (e && atoi(e) == 0) return false;
   const long long M = (long long)p->N * p->H * p->W;
-  return (p->dtype == DP_BF16 || p->dtype == DP_F16) && p->Cin == 128 && p->Cout == 128 && p->Cout_w == 128 && p->ntaps == 9 &&
-         p->Kpad == 1152 && p->stride == 1 && (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == -1 && p->wi_off == -1 &&
-         p->H == p->Ho && p->W == p->Wo && !p->residual && !p->out_f32 && !p->head_out && p->out && p->osW == 128 &&
-         p->osH == (long long)p->W * 128 && p->osN == (long long)p->H * p->W * 128 && M >= 2048 && M * 256 < (1ll << 31);
+  const bool shape = (p->Cin == 128 && p->Cout == 128 && p->Cout_w == 128) || (p->Cin == 256 && p->Cout == 256 && p->Cout_w == 256);
+  const int rp = p->Cin == 128 ? kWsrRP128 : kWsrRP256;
+  return (p->dtype == DP_BF16 || p->dtype == DP_F16) && shape && p->ntaps == 9 && p->Kpad == 9 * p->Cin && p->stride == 1 &&
+         (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == -1 && p->wi_off == -1 && p->H == p->Ho && p->W == p->Wo &&
+         !p->residual && !p->out_f32 && !p->head_out && p->out && p->osW == p->Cout && p->osH == (long long)p->W * p->Cout &&
+         p->osN == (long long)p->H * p->W * p->Cout && p->H >= 2 * rp && M >= 2048 && M * 2 * p->Cin < (1ll << 31);
 }
 
-int dp_conv_ws128_launch(const dp_conv_params* p, dp_stream_t stream) {
-  WsArgs a;
+int dp_conv_wsr_launch(const dp_conv_params* p, dp_stream_t stream) {
+  WsrArgs a;
   a.in = p->in; a.w = p->weight; a.bias = p->bias; a.out = p->out;
-  a.N = p->N; a.H = p->H; a.W = p->W; a.relu = p->relu; a.kpad = p->Kpad;
-  a.n_strips = a.n_seg = a.seg_rows = a.n_jobs = 0;
-  a.bytes = (unsigned)((long long)p->N * p->H * p->W * 256);
+  a.N = p->N; a.H = p->H; a.W = p->W; a.relu = p->relu; a.kpad = p->Kpad; a.cout = p->Cout;
+  a.n_strips = a.spc = a.n_slices = a.n_pg = a.S = 0;
+  a.dbg = nullptr;
+  a.in_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cin * 2);
+  a.out_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cout * 2);
   hipStream_t s = as_stream(stream);
-  return p->dtype == DP_BF16 ? launch_ws<uint16_t>(a, s) : launch_ws<f16_t>(a, s);
+  if (p->Cin == 128) return p->dtype == DP_BF16 ? launch_wsr<uint16_t, 128, kWsrRP128>(a, s) : launch_wsr<f16_t, 128, kWsrRP128>(a, s);
+  return p->dtype == DP_BF16 ? launch_wsr<uint16_t, 256, kWsrRP256>(a, s) : launch_wsr<f16_t, 256, kWsrRP256>(a, s);
 }

@@ -191,9 +191,11 @@ class Engine:
             e0.record(torch.cuda.current_stream(self.device))
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
             e1.record(torch.cuda.current_stream(self.device))
-            cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_ring_kernel<256x256>", "conv_ring_kernel<128x128>", "conv_ring2_kernel<256x128>", "conv1x1_stream_kernel", "conv3x3_ws128_kernel")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
+            cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_ring_kernel<256x256>", "conv_ring_kernel<128x128>", "conv_ring2_kernel<256x128>", "conv1x1_stream_kernel", "conv3x3_wsr_kernel")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
             if cls.startswith("conv_ring_kernel<"):   # one template instance (= one rocprofv3 kernel name) per tile height
                 cls = "conv_ring_kernel<%dx%s" % (self.lib.dp_conv2d_tile_rows(C.byref(p)), cls.split("x")[1])
+            if cls == "conv3x3_wsr_kernel":           # ... and per (channels, ReLU) for the weight-stationary kernel
+                cls = "conv3x3_wsr_kernel<%d,%s>" % (x.C, "relu" if relu else "linear")
             es = x.t.element_size()
             nbytes = (N * (H * W if s == 1 else Ho * Wo * min(layer.ntaps, s * s)) * x.C * es + layer.weight.numel() * es
                       + N * Ho * Wo * layer.cout * (es_out + (es if residual is not None else 0) // (4 if rshift else 1)))

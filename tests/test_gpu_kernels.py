@@ -437,26 +437,31 @@ def test_stem_pool_fused_equals_conv_then_pool(eng, dt, shape):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
-@pytest.mark.parametrize("shape", [(1, 50, 84, True), (2, 37, 45, True), (3, 33, 32, False), (1, 100, 168, True), (2, 64, 35, False), (1, 47, 130, True)])
+@pytest.mark.parametrize("shape", [(128, 1, 50, 84, True), (128, 2, 37, 45, True), (128, 3, 33, 32, False), (128, 1, 100, 168, True),
+                                   (128, 2, 64, 35, False), (128, 1, 47, 130, True), (256, 1, 50, 84, True), (256, 2, 37, 45, False),
+                                   (256, 3, 25, 42, True), (256, 1, 100, 168, False), (256, 2, 64, 35, True), (256, 1, 47, 130, True),
+                                   (256, 8, 13, 32, True), (128, 16, 9, 17, False)])
 def test_conv3x3_weight_stationary_equals_ring_kernel(eng, dt, shape, monkeypatch):
-    """The weight-stationary 3x3 128 -> 128 kernel (res3 conv2, resnet.py:195-197; weights in registers, pixel rows in an LDS ring)
-    against the LDS-ring kernel it replaces - bit-identical (same K order) - and torch in fp64. Odd heights (a last single
-    row), widths that are no multiple of the 16-pixel strip, several images."""
+    """The weight-stationary 3x3 kernels (weights in registers, pixel rows in an LDS ring; C -> C channels, C = 128: res3 conv2,
+    resnet.py:195-197; C = 256: res4 conv2, FPN outputs, decoder) against the LDS-ring kernel they replace - bit-identical
+    (same K order, for C = 256 chained through two waves) - and torch in fp64. Odd heights (a ragged last step), widths that are
+    no multiple of the 16-pixel strip, several images (steps flow across column and image boundaries), more workgroups than steps."""
     from densepose_torchscript_amd import lib as L
     from densepose_torchscript_amd.engine import Act
     from densepose_torchscript_amd.pack import conv_from_oihw
     e = eng[dt]
-    N, H, W, relu = shape
-    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W)
-    x = _round(torch.randn((N, 128, H, W), generator=g), dt)
-    w = _round(torch.randn((128, 128, 3, 3), generator=g) * (1.0 / 1152) ** 0.5, dt)
-    b = torch.randn((128,), generator=g) * 0.3
-    layer = conv_from_oihw("conv2", w.numpy(), b.numpy(), 128, 1, 1, 1, e.dt, e.device)
-    xa = Act(_nhwc(x, 128, e.tdt, e.device), N, H, W, 128)
+    Cc, N, H, W, relu = shape
+    monkeypatch.delenv("DP_CONV_WS", raising=False)
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W + Cc)
+    x = _round(torch.randn((N, Cc, H, W), generator=g), dt)
+    w = _round(torch.randn((Cc, Cc, 3, 3), generator=g) * (1.0 / (9 * Cc)) ** 0.5, dt)
+    b = torch.randn((Cc,), generator=g) * 0.3
+    layer = conv_from_oihw("conv2", w.numpy(), b.numpy(), Cc, 1, 1, 1, e.dt, e.device)
+    xa = Act(_nhwc(x, Cc, e.tdt, e.device), N, H, W, Cc)
     p = L.ConvParams()
-    p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, 128, H, W, 128, 128, 1152
+    p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, Cc, H, W, Cc, Cc, 9 * Cc
     p.stride, p.ntaps, p.dtype, p.hi_off, p.wi_off = 1, 9, e.dt, -1, -1
-    p.osN, p.osH, p.osW = H * W * 128, W * 128, 128
+    p.osN, p.osH, p.osW = H * W * Cc, W * Cc, Cc
     p.out = 1
     assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 6
     got = e.conv(layer, xa, relu=relu)
