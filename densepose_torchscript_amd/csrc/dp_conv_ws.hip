@@ -28,19 +28,29 @@ int ws_num_cus() {
 // 144 VGPRs of a wave, so here nothing about the weights ever moves after the prologue.
 //
 // Every wave keeps 16 output channels x 1152 K values (36 K steps, 144 VGPRs) for the whole launch. With C = 128 that is the
-// whole K axis (8 waves = 128 couts per workgroup); with C = 256 two waves share a cout group: wave h = 0 contracts channel
-// blocks 0..3, hands its accumulators to wave h = 1 (through LDS) which continues with blocks 4..7 - the K order of the packed
-// matrix, so the result is bit-identical to the ring kernels. The chain is pipelined: in iteration i wave h works on step i - h.
-// A workgroup then covers 64 couts and the grid is (cout slice) x (pixel group); the slices of one pixel group sit on one XCD.
+// whole K axis (8 waves = 128 couts per workgroup); with C = 256 two waves share a cout group: the part-0 wave contracts channel
+// blocks 0..3 and hands its accumulators (through LDS) to the part-1 wave, which continues with blocks 4..7 - the K order of the
+// packed matrix, so the result is bit-identical to the ring kernels. The chain is pipelined: in iteration i part h works on step
+// i - h. A workgroup then covers 64 couts and the grid is (cout slice) x (pixel group); the slices of a pixel group share an XCD.
 //   * work = steps (RP output rows of a 16-pixel column strip), numbered strip by strip, top to bottom; a workgroup owns a
 //     contiguous range and NEVER drains between columns: ring rows are addressed by a virtual row number that advances by RP
-//     per step and by 2 more at a column start (the new column's first two rows are fresh);
-//   * input rows travel global -> LDS by LDS-DMA (whole lines, one step ahead, no registers, no ds_write); pixel p's 16-byte
-//     chunk c sits at slot c ^ (2p & 15): fragment reads at any column tap are bank-conflict free (c ^ (p & 15), the first
-//     form's swizzle, costs two LDS cycles per lane group on the centre tap);
+//     per step and by 2 more at a column start (the new column's first two rows are fresh); the bookkeeping is incremental
+//     (no division or modulo in the loop: the first version spent 338 scalar instructions per wave and step on them);
+//   * input rows travel global -> LDS by LDS-DMA (whole lines, one step ahead, no registers, no ds_write). The ring stores a
+//     pixel with a 32-byte pad (pitch 2C + 32): chunk c of pixel p lands on 16-byte slot (2p + c) mod 16, fragment reads at
+//     every column tap are bank-conflict free (SQ_LDS_BANK_CONFLICT = 0) AND the address is affine, so column tap and channel
+//     block are instruction offsets: one ds_read_b128 per fragment, no address arithmetic;
 //   * the weight rows are read un-permuted (A row r of wave group g = logical cout 16 g + r), so the four lanes of a pixel
 //     hold 16 consecutive output channels and the epilogue stores 8 bytes per lane straight from the accumulators: no output
-//     staging buffer, ONE barrier per step.
+//     staging buffer, ONE barrier per step;
+//   * waves w and w + 4 share a SIMD and run in lockstep, so a phase without MFMAs idles the matrix pipe for both. The epilogue
+//     of a step is therefore deferred into the next iteration and, with two K parts, the roles follow the age of the waves
+//     (older = part 1: hand-over read + stores first, then nothing but reads and MFMAs; younger = part 0: MFMAs at once, row
+//     fetches early in its loop under the partner's MFMAs, hand-over write at the end).
+// In-kernel phase stamps (-DDP_EXP=16) on the 200x336 level: 3456 MFMA cycles per SIMD and step out of ~5200; the rest is the
+// issue time of the row fetches (~150 cycles per 1 KiB piece) and the lone tail of the younger wave.
+// A persistent launch with a static split of the work cannot rebalance when it shares the chip with another stream: the host
+// says so (dp_conv_params.shared_chip) and those launches stay on the tiled kernels.
 // =====================================================================================================
 namespace {
 
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
         constexpr int cbl = f / (3 * NQ), q = (f % (3 * NQ)) / 3, dx = f % 3;
         return *reinterpret_cast<const u32x4*>(smem + va[q] + (dx * PP + cbl * 64));
       };
-      constexpr int AHEAD = 6;
+      constexpr int AHEAD = 6;              // fragments in flight ahead of their MFMAs (4 and 8 measure the same within 2 %)
       u32x4 bf[AHEAD + 1];
       static_for<0, AHEAD>([&](auto ff) { bf[decltype(ff)::value] = frag(ff); });
       __builtin_amdgcn_sched_barrier(0);
@@ -416,8 +426,9 @@ constexpr int kWsrRP128 = 4, kWsrRP256 = 3;
 
 // used by dp_conv2d_nhwc (dp_conv.hip): is this launch one of the C -> C 3x3 / pad 1 / stride 1 layers the kernel is written for?
 bool dp_conv_wsr_ok(const dp_conv_params* p) {
-  const char* e = getenv("DP_CONV_WS");    // A/B knob: 0 keeps these layers on the ring kernels
-  if (e && atoi(e) == 0) return false;
+  const char* e = getenv("DP_CONV_WS");    // A/B knob: 0 keeps these layers on the ring kernels, 2 ignores the host's hint
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0 || (mode != 2 && p->shared_chip)) return false;
   const long long M = (long long)p->N * p->H * p->W;
   const bool shape = (p->Cin == 128 && p->Cout == 128 && p->Cout_w == 128) || (p->Cin == 256 && p->Cout == 256 && p->Cout_w == 256);
   const int rp = p->Cin == 128 ? kWsrRP128 : kWsrRP256;

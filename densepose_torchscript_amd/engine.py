@@ -89,6 +89,7 @@ class Engine:
         self.fuse_rpn_head = True     # RPN 3x3 conv + 1x1 heads in one launch where the 256-cout ring kernel runs the level
         self.fuse_bottleneck = True   # res2 blocks: conv2 -> conv3 -> next conv1 in one launch (bottleneck_tail)
         self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
+        self._shared_chip = False     # the launches being issued run beside other large launches (hint to dp_conv2d_nhwc)
         self._side_streams = {}
         self._graphs = {}
         self._pinned = {}
@@ -118,8 +119,12 @@ class Engine:
         s = pool[i]
         s.wait_stream(cur)
         self._forked.setdefault(cur.cuda_stream, set()).add(i)
-        with torch.cuda.stream(s):
-            yield
+        shared, self._shared_chip = self._shared_chip, True    # launches of a branch run beside the main chain (dp_conv_params.shared_chip)
+        try:
+            with torch.cuda.stream(s):
+                yield
+        finally:
+            self._shared_chip = shared
 
     def _join(self, outputs=()):
         cur = torch.cuda.current_stream(self.device)
@@ -185,6 +190,7 @@ class Engine:
         p.dtype = self.dt
         p.out_f32 = 1 if out_f32 else 0
         p.hi_off, p.wi_off = layer.hi_off, layer.wi_off
+        p.shared_chip = 1 if self._shared_chip else 0
         flops = 2 * (layer.macs_per_pixel + (head[2] if head is not None else 0)) * N * Ho * Wo
         if self.prof is not None and N * Ho * Wo > 0:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -633,6 +639,7 @@ class Engine:
             if side is None:
                 side = self._side_streams[cur.cuda_stream] = torch.cuda.Stream(device=self.device)
             side.wait_stream(cur)
+            self._shared_chip = True      # from here to the join the two streams share the chip
             with torch.cuda.stream(side), self._stage("decoder"):
                 dec = self.decoder(feats)
         if given_boxes is None:
@@ -647,6 +654,7 @@ class Engine:
         if side is not None:
             cur.wait_stream(side)
             dec.t.record_stream(cur)
+            self._shared_chip = False
         return dict(n=n, h=h, w=w, feats=feats, det_boxes=det_boxes, det_scores=det_scores, det_counts=det_counts, dec=dec)
 
     def _pinned_counts(self, key, n):

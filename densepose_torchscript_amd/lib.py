@@ -35,7 +35,8 @@ class ConvParams(C.Structure):
                 ("rsN", c_i64), ("rsH", c_i64), ("rsW", c_i64),
                 ("rshift", c_i32), ("relu", c_i32), ("dtype", c_i32), ("out_f32", c_i32),
                 ("hi_off", c_i32), ("wi_off", c_i32), ("stride_w", c_i32),
-                ("head_w", c_void_p), ("head_b", c_void_p), ("head_out", c_void_p)]
+                ("head_w", c_void_p), ("head_b", c_void_p), ("head_out", c_void_p),
+                ("shared_chip", c_i32), ("reserved_", c_i32)]
 
 
 class BottleneckParams(C.Structure):

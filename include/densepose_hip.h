@@ -95,11 +95,18 @@ typedef struct {
   const void* head_w;     /* [16][Cout] dtype, plain row-major (rows = head channels, zero rows for unused ones) */
   const float* head_b;    /* [16] */
   float* head_out;        /* [N*Ho*Wo][16] fp32 */
+  /* Scheduling hint from the host, which knows its stream graph: 0 = this launch has the chip (more or less) to itself,
+   * 1 = it runs beside other large launches on other streams. The weight-stationary 3x3 kernel is a persistent launch with a
+   * static split of the work over the CUs (one workgroup per CU, weights resident in registers): alone on the chip it beats
+   * the tiled kernels, beside another launch it cannot rebalance and loses - with hint 1 the tiled kernels are used. The
+   * result is bit-identical either way. */
+  int32_t shared_chip;
+  int32_t reserved_;
 } dp_conv_params;
 int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
 /* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile,
  * 3 = 128x128 LDS-ring tile, 4 = 256x128 two-workgroup ring tile, 5 = streaming 1x1 (resident weights), 6 = weight-stationary 3x3
- * 128 -> 128 (weights in registers) - profiling / roofline bookkeeping only */
+ * (128 -> 128 / 256 -> 256 channels, weights in registers) - profiling / roofline bookkeeping only */
 int dp_conv2d_kernel_class(const dp_conv_params* p);
 /* pixel rows of the tile dp_conv2d_nhwc will use for these parameters (the 256-cout ring kernel picks 128 .. 256 rows in
  * steps of 32 to fit the launch into whole rounds of the chip) - profiling / roofline bookkeeping only */

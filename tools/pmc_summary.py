@@ -25,6 +25,11 @@ def short(name):
         if m.group(1) == "conv1x1_stream_kernel":
             return "conv1x1_stream_kernel[%s]" % dt
         return "conv_igemm_kernel<%s>[%s]" % (args[1], dt)
+    m = re.search(r"conv3x3_wsr_kernel<([^>]*)>", name)
+    if m:   # <storage type, channels, rows per step, relu>: the class names engine.py / bench.py use
+        args = [a.strip() for a in m.group(1).split(",")]
+        dt = {"unsigned short": "bf16", "_Float16": "f16"}.get(args[0], args[0])
+        return "conv3x3_wsr_kernel<%s,%s>[%s]" % (args[1], "relu" if args[3] in ("true", "1") else "linear", dt)
     m = re.search(r"bottleneck_tail64_kernel<([^>]*)>", name)
     if m:
         args = [a.strip() for a in m.group(1).split(",")]
