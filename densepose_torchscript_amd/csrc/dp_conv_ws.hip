@@ -43,12 +43,13 @@ int ws_num_cus() {
 //   * the weight rows are read un-permuted (A row r of wave group g = logical cout 16 g + r), so the four lanes of a pixel
 //     hold 16 consecutive output channels and the epilogue stores 8 bytes per lane straight from the accumulators: no output
 //     staging buffer, ONE barrier per step;
-//   * waves w and w + 4 share a SIMD and run in lockstep, so a phase without MFMAs idles the matrix pipe for both. The epilogue
-//     of a step is therefore deferred into the next iteration and, with two K parts, the roles follow the age of the waves
-//     (older = part 1: hand-over read + stores first, then nothing but reads and MFMAs; younger = part 0: MFMAs at once, row
-//     fetches early in its loop under the partner's MFMAs, hand-over write at the end).
+//   * waves w and w + 4 share a SIMD and the older one wins the matrix pipe whenever both are ready. Everything that is not a
+//     fragment read or an MFMA sits at the TOP of an iteration, before the wave has LDS reads in flight (an LDS-DMA issued behind
+//     outstanding ds_reads of its wave waits for them): row fetches, the hand-over read, and the PREVIOUS step's stores (the
+//     epilogue is deferred by one iteration). With two K parts the roles follow the age of the waves: older = part 1 (hand-over
+//     read + stores, then a loop of nothing but reads and MFMAs), younger = part 0 (all row fetches, MFMAs, hand-over write).
 // In-kernel phase stamps (-DDP_EXP=16) on the 200x336 level: 3456 MFMA cycles per SIMD and step out of ~5200; the rest is the
-// issue time of the row fetches (~150 cycles per 1 KiB piece) and the lone tail of the younger wave.
+// issue time of the row fetches (~70 cycles per 1 KiB piece up front, ~150 between the MFMAs) and the lone tail of the younger wave.
 // A persistent launch with a static split of the work cannot rebalance when it shares the chip with another stream: the host
 // says so (dp_conv_params.shared_chip) and those launches stay on the tiled kernels.
 // =====================================================================================================
@@ -218,9 +219,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
   wsr_wait_vm<0>();
   __builtin_amdgcn_s_barrier();
 
-  // The epilogue of a step is deferred into the NEXT step's MFMA loop (its accumulators, output offset and row count wait
-  // in registers): the two waves of a SIMD run the same program in lockstep, so a phase without MFMAs idles the matrix pipe
-  // for both. For the same reason the steady-state row fetch is issued piece by piece between the MFMAs.
+  // The epilogue of a step is deferred to the top of the wave's NEXT iteration (its accumulators, output offset and row count
+  // wait in registers): with two K parts it then runs under the latency of the hand-over read, and the end of an iteration -
+  // where the younger wave of every SIMD is the last one computing - has nothing left but the hand-over write.
   f32x4 eacc[RP];
   int e_off = 0, e_rows = 0, e_col = 0;
   bool have_prev = false;
@@ -262,14 +263,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
         va[q] = slot * ROWB + frag_lane;
       }
 
+      // Everything that is not a fragment read or an MFMA happens HERE, before the first LDS read of the iteration is in flight:
+      // an LDS-DMA issued behind outstanding ds_reads of its wave waits for them (measured: ~150 cycles of wave time per piece
+      // between the MFMAs against ~70 up front; 0.567 -> 0.531 ms on the 200x336 level). Order: fetches, then the hand-over
+      // read, then the previous step's stores under its latency - so that at the end of the iteration "all but the last RP
+      // vector-memory operations" still means "every fetch".
       f32x4 acc[RP];
-      const bool fetch_here = fetch_inl && dma_wave;
+      if (fetch_inl && dma_wave) static_for<0, NJ>([&](auto jj) { issue_piece(st_i, jj); });
+      asm volatile("" ::: "memory");      // the fetches stay older than the stores below
       if constexpr (KS > 1) {
         if (h > 0) {
           const unsigned char* hb = smem + HAND + (((g * (KS - 1) + h - 1) * 2 + ((i - 1) & 1)) * RP) * 1024 + lane * 16;
 #pragma unroll
           for (int t = 0; t < RP; ++t) acc[t] = *reinterpret_cast<const f32x4*>(hb + t * 1024);
-          if (had_prev) static_for<0, RP>([&](auto tt) { epi_row(tt); });    // under the hand-over's LDS latency
         } else {
 #pragma unroll
           for (int t = 0; t < RP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -278,6 +284,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
 #pragma unroll
         for (int t = 0; t < RP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      if (had_prev) static_for<0, RP>([&](auto tt) { epi_row(tt); });
+      __builtin_amdgcn_sched_barrier(0);
 
       // fragment f = (channel block cbl, input row q, column tap dx): input row r - 1 + q feeds output row r + t with kernel row q - t
       auto frag = [&](auto ff) __attribute__((always_inline)) -> u32x4 {
@@ -292,25 +300,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
       static_for<0, NF>([&](auto ff) {
         constexpr int f = decltype(ff)::value;
         constexpr int cbl = f / (3 * NQ), q = (f % (3 * NQ)) / 3, dx = f % 3;
-        // Memory instructions between the MFMAs. One K part: fetch pieces in the first half of the loop, the previous step's
-        // stores in the second, so that "all but the last RP vector-memory operations" at the end of the iteration means
-        // "every fetch". Two K parts: the part-0 waves fetch, early in the loop.
-        if constexpr (KS == 1) {
-          constexpr int DJ = (NF / 2) / NJ, DT = (NF / 2) / RP;
-          if constexpr (f < NJ * DJ && f % DJ == DJ / 2) {
-            if (fetch_inl) issue_piece(st_i, std::integral_constant<int, f / DJ>{});
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if constexpr (f >= NF / 2 && f < NF / 2 + RP * DT && (f - NF / 2) % DT == DT / 2) {
-            if (had_prev) epi_row(std::integral_constant<int, (f - NF / 2) / DT>{});
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        } else {
-          if constexpr (f >= 4 && f < 4 + 2 * NJ && f % 2 == 0) {
-            if (fetch_here) issue_piece(st_i, std::integral_constant<int, (f - 4) / 2>{});
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
         // order pinned: the scheduler otherwise sinks every read to one MFMA before its use (lgkmcnt(1) chains)
         if constexpr (f + AHEAD < NF && !(DP_EXP & 1)) bf[(f + AHEAD) % (AHEAD + 1)] = frag(std::integral_constant<int, (f + AHEAD < NF ? f + AHEAD : 0)>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -338,6 +327,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
       }
     } else {
       if (fetch_inl && dma_wave) static_for<0, NJ>([&](auto jj) { issue_piece(st_i, jj); });
+      asm volatile("" ::: "memory");
       if (had_prev) static_for<0, RP>([&](auto tt) { epi_row(tt); });
       have_prev = false;
     }
