@@ -43,6 +43,37 @@ __device__ void bitonic_sort_desc(unsigned long long* s, int n2, int tid, int nt
 // =====================================================================================================
 constexpr int kSelThreads = 1024;
 
+// One step of the MSB-first radix select: the bucket d of a 256-bin histogram that holds the `need`-th largest key - the
+// largest d >= 1 with sum_{j >= d} hist[j] >= need, else 0 - and `above` = the number of keys in the buckets over d.
+// Threads 0..255 of the workgroup each own a bin (suffix sums by wave shuffles + four wave totals); every thread of the
+// workgroup must call it (it contains a barrier). A serial scan by one thread costs up to 255 dependent LDS reads per
+// radix pass - that was most of the 66 / 87 us of the two select kernels.
+__device__ __forceinline__ void radix_pick(const unsigned int* hist, unsigned int need, int tid, unsigned int* wave_tot /*[4]*/,
+                                           unsigned int* out_d, unsigned int* out_above, unsigned int* out_count) {
+  unsigned int h = 0, s = 0;
+  const int lane = tid & 63, w = tid >> 6;
+  if (tid < 256) {
+    h = hist[tid];
+    s = h;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned int v = __shfl_down(s, off, 64);
+      if (lane + off < 64) s += v;
+    }
+    if (lane == 0) wave_tot[w] = s;     // sum of this wave's 64 bins
+  }
+  __syncthreads();
+  if (tid < 256) {
+    for (int ww = w + 1; ww < 4; ++ww) s += wave_tot[ww];    // s = sum_{j >= tid} hist[j]
+    const unsigned int above = s - h;
+    if (above < need && (s >= need || tid == 0)) {           // exactly one bin qualifies
+      *out_d = (unsigned int)tid;
+      *out_above = above;
+      *out_count = h;
+    }
+  }
+}
+
 __global__ void rpn_keys_kernel(const float* __restrict__ head, uint32_t* __restrict__ keys, int n_img, int cells, int A, int head_c) {
   const long long total = (long long)n_img * cells * A;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -64,8 +95,8 @@ __global__ __launch_bounds__(kChunkThreads) void rpn_chunk_select_kernel(const f
                                                                         uint32_t* __restrict__ cand_idx) {
   __shared__ uint32_t keys[kChunk];
   __shared__ unsigned int hist[256];
-  __shared__ unsigned int sh_prefix, sh_need, sh_taken_gt, sh_taken_eq;
-  __shared__ unsigned int wsum_gt[kChunkThreads / 64], wsum_eq[kChunkThreads / 64];
+  __shared__ unsigned int sh_prefix, sh_need, sh_taken_gt, sh_taken_eq, sh_bucket_count;
+  __shared__ unsigned int wsum_gt[kChunkThreads / 64], wsum_eq[kChunkThreads / 64], pick_tot[4];
   const int chunk = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
   const int i0 = chunk * kChunk;
   const int len = min(kChunk, n - i0);
@@ -92,19 +123,10 @@ __global__ __launch_bounds__(kChunkThreads) void rpn_chunk_select_kernel(const f
         if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
       }
       __syncthreads();
-      if (tid == 0) {
-        unsigned int acc = 0;
-        int d = 255;
-        for (; d > 0; --d) {
-          if (acc + hist[d] >= need) break;
-          acc += hist[d];
-        }
-        sh_prefix = prefix | ((uint32_t)d << shift);
-        sh_need = need - acc;
-      }
+      radix_pick(hist, need, tid, pick_tot, &sh_prefix, &sh_need, &sh_bucket_count);   // (bucket, keys above it, keys in it)
       __syncthreads();
-      prefix = sh_prefix;
-      need = sh_need;
+      prefix |= sh_prefix << shift;
+      need -= sh_need;
       mask |= 255u << shift;
       __syncthreads();
     }
@@ -170,7 +192,7 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_kernel(const RpnSelMul
   unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem_raw);  // [n2]
   __shared__ unsigned int hist[256];
   __shared__ unsigned int sh_prefix, sh_need, sh_count, sh_eq_total, sh_eq_taken;
-  __shared__ unsigned int wave_sums[kSelThreads / 64];
+  __shared__ unsigned int wave_sums[kSelThreads / 64], pick_tot[4];
 
   const int img = blockIdx.x, tid = threadIdx.x;
   const int n = p.n_keys;
@@ -200,20 +222,10 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_kernel(const RpnSelMul
         if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
       }
       __syncthreads();
-      if (tid == 0) {
-        unsigned int acc = 0;
-        int d = 255;
-        for (; d > 0; --d) {
-          if (acc + hist[d] >= need) break;
-          acc += hist[d];
-        }
-        sh_prefix = prefix | ((uint32_t)d << shift);
-        sh_need = need - acc;       // how many are still needed inside bucket d
-        sh_eq_total = hist[d];
-      }
+      radix_pick(hist, need, tid, pick_tot, &sh_prefix, &sh_need, &sh_eq_total);   // (bucket d, keys above it, keys in it)
       __syncthreads();
-      prefix = sh_prefix;
-      need = sh_need;
+      prefix |= sh_prefix << shift;
+      need -= sh_need;              // how many are still needed inside bucket d
       mask |= 255u << shift;
       __syncthreads();
     }
@@ -424,6 +436,9 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ 
                                                        int32_t* __restrict__ out_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long* remv = reinterpret_cast<unsigned long long*>(smem_raw);  // [ncb]
+  unsigned long long* kmask = remv + ncb;                                       // [ncb] kept rows of a chunk
+  int* kbase = reinterpret_cast<int*>(kmask + ncb);                             // [ncb] rows kept before the chunk
+  int n_done = 0;
   const int img = blockIdx.x, lane = threadIdx.x;
   const long long base = (long long)img * n_slots;
   const int nvalid = w.nvalid[img];
@@ -431,34 +446,33 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ 
   __syncthreads();
   int kept = 0;
   const int nchunks = (nvalid + 63) / 64;
+  // the diagonal word of the NEXT chunk is fetched before this chunk's resolve: the chunks form one dependent chain
+  // (diagonal word -> resolve -> rows of the kept boxes -> next chunk), every global round trip in it is exposed
+  unsigned long long D_next = (lane < nvalid) ? w.mask[(base + lane) * ncb] : 0ull;
   for (int c = 0; c < nchunks && kept < max_out; ++c) {
     const int row = c * 64 + lane;
-    const bool rvalid = row < nvalid;
-    const unsigned long long D = rvalid ? w.mask[(base + row) * ncb + c] : 0ull;
-    unsigned long long cur = remv[c];
+    const unsigned long long D = D_next;
+    if (c + 1 < nchunks) D_next = (row + 64 < nvalid) ? w.mask[(base + row + 64) * ncb + c + 1] : 0ull;
+    // Greedy resolve of the chunk on the SCALAR unit: the removal word is wave-uniform (readfirstlane tells the compiler so),
+    // and only the rows that are still alive are visited - the next kept row is the lowest set bit of `alive`, its mask word
+    // comes from v_readlane with a scalar lane index. (A 64-step loop on 64-bit VALU values cost ~3 us per chunk.)
+    const unsigned long long cur_v = remv[c];
+    unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur_v >> 32)) << 32) |
+                             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur_v & 0xffffffffull));
     unsigned long long km = 0ull;
     const int rows_here = min(64, nvalid - c * 64);
     const int d_lo = (int)(unsigned)(D & 0xffffffffull), d_hi = (int)(unsigned)(D >> 32);
-    for (int j = 0; j < rows_here; ++j) {
-      // v_readlane with a scalar lane index (j is wave-uniform): no LDS round trip per step
+    unsigned long long alive = ~cur & (rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull));
+    while (alive) {
+      const int j = __ffsll((long long)alive) - 1;
       const unsigned long long dj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(d_hi, j) << 32) |
                                     (unsigned long long)(unsigned)__builtin_amdgcn_readlane(d_lo, j);
-      if (!((cur >> j) & 1ull)) {
-        km |= (1ull << j);
-        cur |= dj;
-      }
+      km |= (1ull << j);
+      alive &= ~(dj | (1ull << j));     // rows below j are already clear, rows above j that j suppresses die
     }
-    // emit kept rows of this chunk in order
-    const bool mine = rvalid && ((km >> lane) & 1ull);
-    const int pos = kept + (int)__popcll(km & ((1ull << lane) - 1ull));
-    if (mine && pos < max_out) {
-      const int slot = w.sslot[base + row];
-      const long long o = (long long)img * max_out + pos;
-      const float* b = boxes + (base + slot) * 4;
-      out_boxes[o * 4 + 0] = b[0]; out_boxes[o * 4 + 1] = b[1]; out_boxes[o * 4 + 2] = b[2]; out_boxes[o * 4 + 3] = b[3];
-      out_scores[o] = scores[base + slot];
-      out_index[o] = slot;
-    }
+    // the kept rows are written out AFTER the chain (their two dependent loads - sort slot, then box - would sit in it)
+    if (lane == 0) { kmask[c] = km; kbase[c] = kept; }
+    n_done = c + 1;
     kept += (int)__popcll(km);
     // OR the kept rows' masks into the removal words of later chunks (lane <-> word)
     if (c + 1 < nchunks && kept < max_out) {
@@ -467,19 +481,41 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ 
         unsigned long long m = km;
         const unsigned long long* col = w.mask + (base + (long long)c * 64) * ncb + wd;
         while (m) {
-          // 4 independent loads per trip (the kept-row list is wave-uniform, so is this control flow)
-          unsigned long long v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-          int j;
-          j = __ffsll((long long)m) - 1; m &= m - 1; v0 = col[(long long)j * ncb];
-          if (m) { j = __ffsll((long long)m) - 1; m &= m - 1; v1 = col[(long long)j * ncb]; }
-          if (m) { j = __ffsll((long long)m) - 1; m &= m - 1; v2 = col[(long long)j * ncb]; }
-          if (m) { j = __ffsll((long long)m) - 1; m &= m - 1; v3 = col[(long long)j * ncb]; }
-          acc |= (v0 | v1) | (v2 | v3);
+          // 32 independent loads per trip (the kept-row list is wave-uniform, so is this control flow): the trip count, not
+          // the bytes, sets the time of this phase - each trip waits for one L2 round trip (4 per trip: 238 us for the RPN's
+          // launch, 16 per trip: 176 us)
+          unsigned long long v[32];
+#pragma unroll
+          for (int u = 0; u < 32; ++u) {
+            v[u] = 0ull;
+            if (m) {
+              const int j = __ffsll((long long)m) - 1;
+              m &= m - 1;
+              v[u] = col[(long long)j * ncb];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 32; ++u) acc |= v[u];
         }
         remv[wd] = acc;
       }
     }
     __syncthreads();
+  }
+  __syncthreads();
+  // emit the kept rows of every processed chunk in order: position = kept rows before the chunk + kept rows before me in it
+  for (int c = 0; c < n_done; ++c) {
+    const int row = c * 64 + lane;
+    const unsigned long long km = kmask[c];
+    const int pos = kbase[c] + (int)__popcll(km & ((1ull << lane) - 1ull));
+    if (row < nvalid && ((km >> lane) & 1ull) && pos < max_out) {
+      const int slot = w.sslot[base + row];
+      const long long o = (long long)img * max_out + pos;
+      const float* b = boxes + (base + slot) * 4;
+      out_boxes[o * 4 + 0] = b[0]; out_boxes[o * 4 + 1] = b[1]; out_boxes[o * 4 + 2] = b[2]; out_boxes[o * 4 + 3] = b[3];
+      out_scores[o] = scores[base + slot];
+      out_index[o] = slot;
+    }
   }
   if (lane == 0) out_count[img] = kept < max_out ? kept : max_out;
 }
@@ -744,7 +780,7 @@ extern "C" int dp_batched_nms(const dp_nms_params* p, dp_stream_t stream) {
   hipLaunchKernelGGL(nms_sort_kernel, dim3(p->n_img), dim3(kSortThreads), n2 * 8, s, p->boxes, p->scores, p->group, p->valid, p->n_slots, n2,
                      p->trick_max_numel, w);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb, ncb, p->n_img), dim3(64), 0, s, p->n_slots, ncb, p->iou_thr, w);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(p->n_img), dim3(64), ncb * 8, s, p->boxes, p->scores, p->n_slots, ncb, p->max_out, w, p->out_boxes,
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(p->n_img), dim3(64), ncb * 20, s, p->boxes, p->scores, p->n_slots, ncb, p->max_out, w, p->out_boxes,
                      p->out_scores, p->out_index, p->out_count);
   return dp_check_launch("nms kernels");
 }
