@@ -111,9 +111,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   // cout group and K part. Waves w and w + 4 share a SIMD and the older one (w < 4) wins the matrix pipe whenever both are
-  // ready. With two K parts the older wave takes part 1: it first fetches the handed-over accumulators and stores the previous
-  // step's outputs while its partner (part 0: nothing to wait for) already runs MFMAs, then runs a loop of nothing but reads and
-  // MFMAs; the younger wave issues the row fetches early in ITS loop - under the older wave's MFMAs - and hands its sums over.
+  // ready. With two K parts the older wave takes part 1 (hand-over read + the previous step's stores at the top of its
+  // iteration) and the younger wave part 0 (every row fetch at the top of its iteration, hand-over write at the end).
   const int g = wave % NG, h = KS == 1 ? 0 : 1 - wave / NG;
   const int b = blockIdx.x;
   const int slice = (b >> 3) % p.n_slices;
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
   // Fetching the rows of a step that are not in the ring yet: whole 1 KiB pieces of ring rows; the lanes that fall on a pixel's
   // pad or outside the image read zeros (out-of-range buffer offset). In the steady state (RP new rows) piece j of this wave is
   // always the same (row, piece-in-row), so its per-lane part is computed once: staged pixel and byte offset inside the row.
-  // With two K parts the part-0 waves issue every fetch (spread over their MFMA loop) and the part-1 waves every store.
+  // With two K parts the part-0 waves issue every fetch and the part-1 waves every store.
   constexpr int ND = KS == 1 ? 8 : NG;         // fetching waves
   constexpr int NJ = (RP * PPR + ND - 1) / ND; // pieces per fetching wave and step
   const bool dma_wave = h == 0;
