@@ -50,8 +50,9 @@ int ws_num_cus() {
 //     read + stores, then a loop of nothing but reads and MFMAs), younger = part 0 (all row fetches, MFMAs, hand-over write).
 // In-kernel phase stamps (-DDP_EXP=16) on the 200x336 level: 3456 MFMA cycles per SIMD and step out of ~5200; the rest is the
 // issue time of the row fetches (~70 cycles per 1 KiB piece up front, ~150 between the MFMAs) and the lone tail of the younger wave.
-// A persistent launch with a static split of the work cannot rebalance when it shares the chip with another stream: the host
-// says so (dp_conv_params.shared_chip) and those launches stay on the tiled kernels.
+// A persistent launch with a static split over exactly as many workgroups as CUs cannot rebalance when it shares the chip with
+// another stream: the host says so (dp_conv_params.shared_chip) and those launches are split over twice as many workgroups
+// (DESIGN.md section 4.1c).
 // =====================================================================================================
 namespace {
 
@@ -65,6 +66,7 @@ struct WsrArgs {
   int N, H, W, relu, kpad, cout;
   int n_strips, spc, n_slices, n_pg;
   int S;                       // steps per cout slice
+  int over;                    // workgroups per CU slot (1 = one persistent workgroup per CU)
   unsigned in_bytes, out_bytes;
   unsigned long long* dbg;     // diagnostic builds (-DDP_EXP=16): per-wave phase cycle sums
 };
@@ -374,7 +376,7 @@ int launch_wsr_r(WsrArgs a, hipStream_t stream) {
   a.n_slices = a.cout / CS;
   int groups = cus / (8 * a.n_slices);
   if (groups < 1) groups = 1;
-  a.n_pg = groups * 8;
+  a.n_pg = groups * 8 * (a.over > 1 ? a.over : 1);     // over-decomposition: more, shorter workgroups than CUs
   a.dbg = nullptr;
 #if DP_EXP & 16
   static unsigned long long* dbg = nullptr;
@@ -415,9 +417,9 @@ constexpr int kWsrRP128 = 4, kWsrRP256 = 3;
 
 // used by dp_conv2d_nhwc (dp_conv.hip): is this launch one of the C -> C 3x3 / pad 1 / stride 1 layers the kernel is written for?
 bool dp_conv_wsr_ok(const dp_conv_params* p) {
-  const char* e = getenv("DP_CONV_WS");    // A/B knob: 0 keeps these layers on the ring kernels, 2 ignores the host's hint
+  const char* e = getenv("DP_CONV_WS");    // A/B knob: 0 keeps these layers on the ring kernels, 4 only those that share the chip
   const int mode = e ? atoi(e) : 1;
-  if (mode == 0 || (mode != 2 && p->shared_chip)) return false;
+  if (mode == 0 || (mode == 4 && p->shared_chip)) return false;
   const long long M = (long long)p->N * p->H * p->W;
   const bool shape = (p->Cin == 128 && p->Cout == 128 && p->Cout_w == 128) || (p->Cin == 256 && p->Cout == 256 && p->Cout_w == 256);
   const int rp = p->Cin == 128 ? kWsrRP128 : kWsrRP256;
@@ -433,6 +435,16 @@ int dp_conv_wsr_launch(const dp_conv_params* p, dp_stream_t stream) {
   a.N = p->N; a.H = p->H; a.W = p->W; a.relu = p->relu; a.kpad = p->Kpad; a.cout = p->Cout;
   a.n_strips = a.spc = a.n_slices = a.n_pg = a.S = 0;
   a.dbg = nullptr;
+  {
+    // A launch that has the chip to itself: one persistent workgroup per CU. One that runs beside another stream's launches
+    // (dp_conv_params.shared_chip): two workgroups per CU slot, each with half the steps - a static split over exactly as many
+    // workgroups as CUs cannot rebalance when some CUs are taken, the dispatcher can with workgroups to spare; the price is a
+    // second weight prologue per CU (A/B knobs for both cases).
+    const char* es = getenv("DP_WS_OVER_SHARED");
+    const char* ea = getenv("DP_WS_OVER_ALONE");
+    a.over = p->shared_chip ? (es ? atoi(es) : 2) : (ea ? atoi(ea) : 1);
+    if (a.over < 1) a.over = 1;
+  }
   a.in_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cin * 2);
   a.out_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cout * 2);
   hipStream_t s = as_stream(stream);

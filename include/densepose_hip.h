@@ -97,9 +97,10 @@ typedef struct {
   float* head_out;        /* [N*Ho*Wo][16] fp32 */
   /* Scheduling hint from the host, which knows its stream graph: 0 = this launch has the chip (more or less) to itself,
    * 1 = it runs beside other large launches on other streams. The weight-stationary 3x3 kernel is a persistent launch with a
-   * static split of the work over the CUs (one workgroup per CU, weights resident in registers): alone on the chip it beats
-   * the tiled kernels, beside another launch it cannot rebalance and loses - with hint 1 the tiled kernels are used. The
-   * result is bit-identical either way. */
+   * static split of the work over its workgroups (weights resident in registers): alone on the chip it runs one workgroup per
+   * CU; with hint 1 it is split over twice as many, shorter workgroups so that the dispatcher can rebalance when some CUs are
+   * held by another stream (a one-per-CU split cannot, and loses its advantage over the tiled kernels). The result is
+   * bit-identical either way. */
   int32_t shared_chip;
   int32_t reserved_;
 } dp_conv_params;
