@@ -22,7 +22,8 @@ FPN_STRIDES = (4, 8, 16, 32, 64)
 # (run.py:22-29). At 800x1333 the RPN feeds 4 x 4819 = 19276 elements: per-level loop on the CPU, trick on CUDA; the two
 # differ only where an IoU sits within rounding of the threshold. Engine.nms_reference picks the one to reproduce.
 NMS_TRICK_MAX_NUMEL = {"cpu": 4000, "cuda": 20000}
-MAX_GRAPHS = 4   # captured HIP graphs kept per engine (each pins the activations of its shape): least recently used is dropped
+MAX_GRAPHS = 8   # captured HIP graphs kept per engine (each pins the activations of its shape): least recently used is dropped;
+                 # raised to the number of live (stream slot, pipeline lane) pairs when that is larger (Engine._graph_cap)
 
 _engine_device = None   # the one device this process drives (one process per GPU: DESIGN.md §5)
 
@@ -92,6 +93,7 @@ class Engine:
         self._shared_chip = False     # the launches being issued run beside other large launches (hint to dp_conv2d_nhwc)
         self._side_streams = {}
         self._graphs = {}
+        self._graph_slots, self._graph_captures = set(), {}
         self._pinned = {}
 
     # ------------------------------------------------------------------ helpers
@@ -363,6 +365,9 @@ class Engine:
                     feats["p2"] = self.conv(Ls["fpn_output2"], prev)
                     continue
                 with self._branch(bi, 1):
+                    # the branch READS `prev` on a side stream while the loop rebinds the name: without this the caching allocator
+                    # could hand the block to a later main-stream allocation before the side-stream conv has read it
+                    prev.t.record_stream(torch.cuda.current_stream(self.device))
                     feats["p%d" % lvl] = self.conv(Ls["fpn_output%d" % lvl], prev)
                     outs.append(feats["p%d" % lvl].t)
                     if lvl == 5:
@@ -679,7 +684,15 @@ class Engine:
             key = (tuple(images_u8.shape), slot, self.overlap_decoder, self.fuse_bottleneck, self.fuse_rpn_head, self.fuse_stem_pool, self.fork_levels, self.nms_reference)
             entry = self._graphs.pop(key, None)
             if entry is None:
-                while len(self._graphs) >= MAX_GRAPHS:      # drop the least recently used graph and its memory pool
+                # every (stream slot / pipeline lane) of one geometry needs a graph of its own: never cap below the slots in use,
+                # and say so when the same key keeps being re-captured (a recapture costs a device synchronise + an eager run)
+                self._graph_slots.add(slot)
+                ncap = self._graph_captures[key] = self._graph_captures.get(key, 0) + 1
+                if ncap == 3:
+                    import warnings
+                    warnings.warn("HIP graph of %s captured %d times: more live (geometry, slot) pairs than the graph cache holds - "
+                                  "run such a stream eagerly (use_graphs=False) or with fewer streams" % (key[:2], ncap))
+                while len(self._graphs) >= max(MAX_GRAPHS, 2 * len(self._graph_slots)):      # drop the least recently used graph and its memory pool
                     torch.cuda.synchronize(self.device)     # (rare: a new input geometry) its last replay may still be running
                     old = self._graphs.pop(next(iter(self._graphs)))
                     self._pinned.pop(old[5], None)

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("DP_HIP_LIB") or os.path.join(_HERE, "libdensepose_hip
 CSRC = os.path.join(_HERE, "csrc")
 
 DP_F32, DP_BF16, DP_F16 = 0, 1, 2
+ABI_VERSION = 3   # == DP_ABI_VERSION of include/densepose_hip.h (bumped whenever a params struct or the symbol set changes)
 
 # user-facing dtype names -> (enum, element size)
 DTYPES = {"fp32": DP_F32, "float32": DP_F32, "bf16": DP_BF16, "bfloat16": DP_BF16, "fp16": DP_F16, "float16": DP_F16, "half": DP_F16}
@@ -194,10 +195,10 @@ def build_library(force=False):
 _lib = None
 
 
-if __name__ == "__main__":   # `python lib.py stamp`: record the source digest beside a library built by hand (make)
+if __name__ == "__main__":   # `python lib.py stamp [LIB]`: record the source digest beside a library built by hand (make)
     import sys
-    if sys.argv[1:] == ["stamp"]:
-        with open(LIB_PATH + ".sha256", "w") as f:
+    if sys.argv[1:2] == ["stamp"]:
+        with open((sys.argv[2] if len(sys.argv) > 2 else LIB_PATH) + ".sha256", "w") as f:
             f.write(_source_digest() + "\n")
 
 
@@ -209,13 +210,23 @@ def load():
         raise DensePoseHipError(
             "HIP kernel library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback in the product path)" % LIB_PATH)
+    # A library built from other sources than the ones in this tree may lay its params structs out differently while exporting
+    # the same symbols (the version number only moves when somebody remembers to bump it): the digest recorded at build time
+    # must match the sources this binding was written against. DP_SKIP_STAMP_CHECK=1 is for hand-made experiment builds.
+    if os.environ.get("DP_SKIP_STAMP_CHECK", "0") != "1":
+        stamp = LIB_PATH + ".sha256"
+        have = open(stamp).read().strip() if os.path.exists(stamp) else None
+        if have != _source_digest():
+            raise DensePoseHipError(
+                "%s was not built from the sources in this tree (digest %s, sources %s): rebuild it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'`" % (LIB_PATH, have and have[:12], _source_digest()[:12]))
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.dp_abi_version() != 1:
-        raise DensePoseHipError("ABI version mismatch")
+    if lib.dp_abi_version() != ABI_VERSION:
+        raise DensePoseHipError("ABI version mismatch: library %d, binding %d" % (lib.dp_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

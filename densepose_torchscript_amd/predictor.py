@@ -20,6 +20,60 @@ from .resize import resize_u8_device_batch
 from .weights import check_state, load_checkpoint
 
 
+class _HostFrameRing:
+    """Pinned staging slots for HOST-resident frames (the reference's boundary hands over CPU tensors: defaults.py:65-80,
+    run.py:34-36). A pageable tensor cannot be copied asynchronously - `.to(device, non_blocking=True)` on it stages through
+    the driver's own bounce buffer on the caller's thread and stream. Here the frames of a batch are gathered into one
+    page-locked buffer (one host memcpy each, torch's multi-threaded copy), ONE H2D transfer per batch runs on a dedicated
+    copy stream, and the compute lane only waits for its event: the upload of batch i + 1 overlaps the kernels of batch i.
+    `slots` buffers per frame geometry rotate; a slot is rewritten only after its previous upload has completed (host wait on
+    its event, normally long past) and its device landing buffer only after the resize kernel that read it has run."""
+
+    def __init__(self, device, slots=3, workers=4):
+        self.device, self.n_slots = device, slots
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.rings = {}      # (n, frame shape) -> [slot dicts]
+        self.cursor = {}
+        # the gather into the pinned slot is plain memcpy work: a few worker threads (ctypes.memmove releases the GIL) instead of
+        # torch's copy_, whose OpenMP region over every core of a 256-thread host costs milliseconds per 3 MB frame
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=workers)
+
+    @staticmethod
+    def _gather_one(dst, src):
+        if src.is_contiguous():
+            import ctypes
+            ctypes.memmove(dst.data_ptr(), src.data_ptr(), src.numel())
+        else:
+            dst.copy_(src)
+
+    def upload(self, frames, consumer_stream):
+        """frames: list of equal-shape CPU uint8 tensors (any strides). -> (device tensor [n, *shape], slot); the caller records
+        slot["consumed"] on the stream that read the device tensor once its kernel is launched."""
+        key = (len(frames), tuple(frames[0].shape))
+        ring = self.rings.get(key)
+        if ring is None:
+            ring = self.rings[key] = [
+                {"pinned": torch.empty((len(frames),) + tuple(frames[0].shape), dtype=torch.uint8, pin_memory=True),
+                 "dev": torch.empty((len(frames),) + tuple(frames[0].shape), dtype=torch.uint8, device=self.device),
+                 "h2d_done": torch.cuda.Event(), "consumed": torch.cuda.Event(), "used": False}
+                for _ in range(self.n_slots)]
+            self.cursor[key] = 0
+        slot = ring[self.cursor[key]]
+        self.cursor[key] = (self.cursor[key] + 1) % self.n_slots
+        if slot["used"]:
+            slot["h2d_done"].synchronize()                  # the previous upload out of this pinned buffer has finished
+            self.copy_stream.wait_event(slot["consumed"])   # ... and the kernel that read the landing buffer has run
+        # host memcpy into the page-locked slot (a strided view is laid out contiguously by copy_ instead)
+        list(self.pool.map(self._gather_one, [slot["pinned"][i] for i in range(len(frames))], frames))
+        with torch.cuda.stream(self.copy_stream):
+            slot["dev"].copy_(slot["pinned"], non_blocking=True)
+            slot["h2d_done"].record(self.copy_stream)
+        consumer_stream.wait_event(slot["h2d_done"])
+        slot["used"] = True
+        return slot["dev"], slot
+
+
 class DensePosePredictor:
     def __init__(self, cfg, weights, dtype="bf16", device="cuda:0", resize="host", num_streams=1, use_graphs=False, check_keep=False,
                  pipeline_depth=1, nms_reference="cpu"):
@@ -54,6 +108,7 @@ class DensePosePredictor:
         self.pipeline_depth = pipeline_depth
         self._lanes, self._next_lane = [], 0
         self._last_done = []   # completion events of the most recent predict_batch call (one per frame group)
+        self._host_ring = None  # _HostFrameRing, created on the first host-resident frame
 
     # -- defaults.py:76-89 ---------------------------------------------------------------------------------
     def _to_chw(self, original_image, bgr):
@@ -73,13 +128,29 @@ class DensePosePredictor:
         """chws: CHW views of ONE geometry -> uint8 [n,3,oh,ow] on the device (defaults.py:89, once per frame there)."""
         height, width = int(chws[0].shape[1]), int(chws[0].shape[2])
         k = self._scale(height, width)
+        cur = torch.cuda.current_stream(self.device)
         if self.resize_mode == "device":
             # permuted views of contiguous HWC frames are resized straight from HWC
             hwc = all(c.stride(0) == 1 and c.stride(2) == 3 for c in chws)
-            frames = [(c.permute(1, 2, 0) if hwc else c).to(self.device, non_blocking=True) for c in chws]
+            views = [(c.permute(1, 2, 0) if hwc else c) for c in chws]
+            if all(not v.is_cuda for v in views):
+                # host-resident frames (the reference's boundary): pinned ring + one H2D per batch on the copy stream
+                if self._host_ring is None:
+                    self._host_ring = _HostFrameRing(self.device)
+                dev, slot = self._host_ring.upload(views, cur)
+                out = resize_u8_device_batch(self.engine, [dev[i] for i in range(len(views))], k, src_hwc=hwc)
+                slot["consumed"].record(cur)
+                return out
+            frames = [v.to(self.device, non_blocking=True) for v in views]
             return resize_u8_device_batch(self.engine, frames, k, src_hwc=hwc)
-        return torch.stack([F.interpolate(c.cpu()[None], scale_factor=k, mode="bilinear", align_corners=False)[0] for c in chws]
-                           ).to(self.device, non_blocking=True)
+        # "host": torch's CPU uint8 kernel exactly as the reference runs it; the resized frames go up through the same ring
+        small = [F.interpolate(c.cpu()[None], scale_factor=k, mode="bilinear", align_corners=False)[0] for c in chws]
+        if self._host_ring is None:
+            self._host_ring = _HostFrameRing(self.device)
+        dev, slot = self._host_ring.upload(small, cur)
+        out = dev.clone()                    # the batch tensor outlives the slot (graph replay copies from it later)
+        slot["consumed"].record(cur)
+        return out
 
     @torch.no_grad()
     def __call__(self, original_image, bgr=True):

@@ -37,7 +37,7 @@ enum dp_status {
   DP_ERR_LAUNCH = -3        /* hipGetLastError() after launch */
 };
 
-#define DP_ABI_VERSION 1
+#define DP_ABI_VERSION 3
 int dp_abi_version(void);
 /* human-readable reason of the last non-zero return on this thread */
 const char* dp_last_error(void);

@@ -57,6 +57,13 @@ CASES = {
 }
 
 
+# The reference's OWN fp16 mode (run.py:26 / export.py:36-37: `predictor.half()`), run on the CPU: ATen's CPU kernels take half
+# tensors (accumulating in float, rounding every layer's output to half). Recorded for cases that also have an fp32 golden, as
+# `<case>__half.npz` (outputs + visualiser labels only): the distance fp16-reference <-> fp32-reference is the yardstick the
+# engine's fp16 mode is held to (tests/test_gpu_e2e.py), and the engine must be about as close to this golden as to the fp32 one.
+HALF_CASES = ["tiny_r50_s1x_a", "full_r50_s1x_small", "tiny_r50_dl"]
+
+
 def make_image(seed, hw):
     return np.random.default_rng(seed).integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)
 
@@ -69,6 +76,32 @@ def _import_visualizer():
     sys.path.insert(0, REFERENCE_ROOT)
     import visualizer  # noqa
     return visualizer
+
+
+def run_half_case(name):
+    cfg_name, opts, wseed, iseed, hw, stages, sub = CASES[name]
+    cfg = get_config(cfg_name, opts)
+    state = make_synthetic_state(cfg, wseed)
+    pred = build_reference_predictor(cfg, state).half()
+    out = pred(torch.from_numpy(make_image(iseed, hw)))
+    arrays = {}
+    for k, v in out.items():
+        a = v.float().numpy() if v.is_floating_point() else v.numpy()
+        if k.startswith("pred_densepose") and sub > 1:
+            a = a[:, :, ::sub, ::sub]
+        arrays["out/" + k] = a
+        arrays["dtype/" + k] = np.frombuffer(str(v.dtype).encode(), dtype=np.uint8)
+    vis = _import_visualizer()
+    results, _ = vis.DensePoseResultExtractor()({k: (v.float() if v.is_floating_point() else v) for k, v in out.items()})
+    for i, r in enumerate(results):
+        arrays["vis/labels_%d" % i] = r["labels"].numpy().astype(np.uint8)
+    meta = dict(case=name + "__half", config=cfg_name, opts=list(opts), weight_seed=wseed, image_seed=iseed, image_hw=list(hw),
+                iuv_stride=sub, weights_sha256=state_checksum(state), torch=torch.__version__, mode="reference .half() on CPU",
+                generator="oracle/make_goldens.py --half (reference imported from /root/reference)")
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(GOLDEN_DIR, name + "__half.npz")
+    np.savez_compressed(path, **arrays)
+    print("%-26s R=%d  %.2f MB (half)" % (name, len(out["scores"]), os.path.getsize(path) / 1e6), flush=True)
 
 
 def run_case(name):
@@ -148,9 +181,15 @@ def run_case(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--half", action="store_true", help="record the <case>__half.npz fixtures (reference .half() on CPU) instead")
     args = ap.parse_args()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
+    if args.half:
+        for name in HALF_CASES:
+            if not args.only or args.only == name:
+                run_half_case(name)
+        return
     for name in CASES:
         if args.only and args.only != name:
             continue

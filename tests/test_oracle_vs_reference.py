@@ -55,3 +55,32 @@ def test_caffe2_name_conversion_equals_reference():
     assert {k for k in mine if k not in theirs} == {k for k in mine if k.endswith("running_mean") or k.endswith("running_var")}
     for k, v in theirs.items():
         assert np.array_equal(v.numpy(), mine[k]), k
+
+
+@pytest.mark.parametrize("name,wseed", [("densepose_rcnn_R_50_FPN_s1x", 17), ("densepose_rcnn_R_50_FPN_s1x_legacy", 18),
+                                        ("densepose_rcnn_R_101_FPN_DL_s1x", 19)])
+def test_load_checkpoint_reads_the_reference_state_dict(name, wseed, tmp_path):
+    """weights.load_checkpoint on what the reference itself would save - `DefaultPredictor.state_dict()` as a torch `.pth`
+    (bare and wrapped in {"model": ...}) and as a detectron2-style `.pkl` ({"model", "__author__"}, detection_checkpoint.py:53-64) -
+    gives back the canonical state: the TorchScript fork's ModuleList aliases (stages.N / lateral_convs.N / ...) collapse onto
+    the canonical names, the `model.` prefix, pixel_mean / pixel_std and the anchor buffers are dropped, values are untouched."""
+    import pickle
+    from densepose_torchscript_amd.config import TINY_OPTS, get_config
+    from densepose_torchscript_amd.weights import check_state, load_checkpoint, make_synthetic_state, param_shapes
+    from oracle.ref_import import build_reference_predictor
+    cfg = get_config(name, TINY_OPTS)
+    state = make_synthetic_state(cfg, wseed)
+    sd = build_reference_predictor(cfg, state).state_dict()
+    assert len(sd) > len(state)                         # the aliases are really there
+    shapes = param_shapes(cfg)
+    pth, pth_wrapped, pkl = str(tmp_path / "m.pth"), str(tmp_path / "w.pth"), str(tmp_path / "m.pkl")
+    torch.save(sd, pth)
+    torch.save({"model": sd, "iteration": 7}, pth_wrapped)
+    with open(pkl, "wb") as f:
+        pickle.dump({"model": {k: v.numpy() for k, v in sd.items()}, "__author__": "reference state_dict"}, f, protocol=2)
+    for path in (pth, pth_wrapped, pkl):
+        got = load_checkpoint(path, cfg)
+        assert check_state(cfg, got) == []              # nothing missing, nothing mis-shaped, nothing unknown
+        assert set(got) == set(shapes) == set(state)
+        for k in shapes:
+            assert got[k].dtype == np.float32 and np.array_equal(got[k], state[k]), (path, k)
