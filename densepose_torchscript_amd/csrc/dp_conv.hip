@@ -52,6 +52,7 @@ struct ConvArgs {
   int M, tiles_n, n_ktiles, HoWo, n_tiles;
   unsigned in_bytes, w_bytes, res_bytes;   // buffer-resource extents (ring / streaming kernels)
   int ntaps, out_linear, res_linear;
+  const int* n_dev;       // device-side count of live images (dp_conv_params.n_dev): tiles that start behind them exit at once
   const void* head_w;     // fused 1x1 head (RPN): plain [16][Cout] storage type, rows = head channels
   const float* head_b;    // [16]
   float* head_out;        // [M][16] fp32
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs 
   const int nt = tile - mt * p.tiles_n;
   const int m0 = mt * kBM;
   const int n0 = nt * BN;
+  if (p.n_dev != nullptr && m0 >= *p.n_dev * p.HoWo) return;   // (uniform: a scalar load) nothing live in this tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -335,6 +337,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
   const int nt = tile - mt * p.tiles_n;
   const int m0 = mt * BM;
   const int n0 = nt * BN;
+  if (p.n_dev != nullptr && m0 >= *p.n_dev * p.HoWo) return;   // (uniform: a scalar load) nothing live in this tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -637,6 +640,7 @@ __global__ __launch_bounds__(512, 4) void conv_ring2_kernel(const ConvArgs p) {
   const int nt = tile - mt * p.tiles_n;
   const int m0 = mt * BM;
   const int n0 = nt * BN;
+  if (p.n_dev != nullptr && m0 >= *p.n_dev * p.HoWo) return;   // (uniform: a scalar load) nothing live in this tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1103,6 +1107,7 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   a.res_bytes = p->residual ? (unsigned)((long long)p->N * p->rsN * es) : 0u;
   a.ntaps = p->ntaps;
   a.head_w = p->head_w; a.head_b = p->head_b; a.head_out = p->head_out;
+  a.n_dev = p->n_dev;
   a.out_linear = (p->osH == (long long)p->Wo * p->osW && p->osN == (long long)p->Ho * p->osH) ? 1 : 0;
   a.res_linear = (p->residual && p->rshift == 0 && p->rsH == (long long)p->Wo * p->rsW && p->rsN == (long long)p->Ho * p->rsH) ? 1 : 0;
   hipStream_t s = as_stream(stream);
@@ -1114,6 +1119,9 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
       return dp_fail(DP_ERR_UNSUPPORTED, "dp_conv2d_nhwc: the fused head needs the 256-cout ring kernel (Cout 256, 16-bit storage, ReLU, no residual)");
   }
   if (kc == DP_CONV_WSR) return dp_conv_wsr_launch(p, stream);
+  if (p->post_res || p->post_mode)
+    return dp_fail(DP_ERR_UNSUPPORTED, "dp_conv2d_nhwc: post_res (a tensor added after the activation) is implemented by the weight-stationary 3x3 kernel only "
+                                        "(256 -> 256 channels, ReLU, 16-bit storage; post_mode 2 needs even H and W)");
   if (kc == DP_CONV_STREAM) {
     a.tiles_n = p->Cout / 256;
     a.n_tiles = 0;

@@ -68,6 +68,9 @@ struct WsrArgs {
   int S;                       // steps per cout slice
   int over;                    // workgroups per CU slot (1 = one persistent workgroup per CU)
   unsigned in_bytes, out_bytes;
+  const void* post;            // tensor added after the activation (dp_conv_params.post_res): POST = 1 output geometry, 2 = half size, bilinear x2
+  int Hl, Wl;                  // POST = 2: geometry of the half-size map
+  unsigned post_bytes;
   unsigned long long* dbg;     // diagnostic builds (-DDP_EXP=16): per-wave phase cycle sums
 };
 
@@ -79,7 +82,10 @@ __device__ __forceinline__ void wsr_wait_vm() {
   else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else { static_assert(N == 8, "vmcnt immediate"); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
 }
 
 // step bookkeeping without divisions: a step's image, first column, first output row and the ring row (virtual row modulo the
@@ -88,7 +94,19 @@ struct WsrStep {
   int n, c0, r, um, first;
 };
 
-template <typename T, int C, int RP, bool RELU>
+// ATen's bilinear x2 source index / weight (align_corners = False): src = max((o + 0.5) * 0.5 - 0.5, 0) - the formula of dp_ops.hip
+__device__ __forceinline__ void wsr_bil_src(int o, int n, int& i0, int& i1, float& l) {
+  float s = ((float)o + 0.5f) * 0.5f - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  l = s - (float)i0;
+}
+
+// POST: 0 = plain, 1 = out = act(..) + post[same pixel], 2 = out = act(..) + bilinear_x2(post) (the decoder's level sum).
+// The post values of a step are loaded at the top of the iteration that COMPUTES the step and consumed by its (deferred)
+// epilogue one iteration later: a whole MFMA phase hides their latency.
+template <typename T, int C, int RP, bool RELU, int POST>
 __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
   static_assert(C == 128 || C == 256, "channel counts the register budget covers");
@@ -139,6 +157,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
 
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_post = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(POST ? p.post : p.in), 0, POST ? p.post_bytes : 0u, 0x00020000);
 
   const int frag_lane = fr * PP + fq * 16 + h * 256;     // lane part of a fragment address: pixel fr, chunk h * 16 + fq
   const int n_cols = p.n_strips * 16;
@@ -227,6 +246,52 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
   int e_off = 0, e_rows = 0, e_col = 0;
   bool have_prev = false;
   const int opix = p.cout * 2;
+  // post tensor values of the step whose epilogue is pending. POST = 1: the 4 channels of this lane's pixel in each output row.
+  // POST = 2: the three half-size rows b, b + 1, b + 2 (b = first source row of the step's first output row; clamped) that the
+  // RP <= 3 output rows interpolate between, at this lane's two source columns.
+  constexpr int NPV = POST == 1 ? RP : (POST == 2 ? 6 : 1);
+  static_assert(POST != 2 || RP <= 3, "three half-size rows cover at most three output rows");
+  constexpr int NPL = POST == 1 ? RP : (POST == 2 ? 6 : 0);   // post loads per step of a storing wave
+  u32x2 pv[NPV];
+  int e_r = 0, e_b = 0;          // POST = 2: first output row of the pending step, its base half-size row
+  float p_lx = 0.f;              // POST = 2: this lane's horizontal weight
+  auto post_issue = [&](const WsrStep& st) __attribute__((always_inline)) {
+    if constexpr (POST == 1) {
+      const int col = st.c0 + fr;
+      const int off = ((st.n * p.H + st.r) * p.W + col) * opix + (cbase + fq * 4) * 2;
+#pragma unroll
+      for (int t = 0; t < RP; ++t)
+        pv[t] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, (st.r + t < p.H && col < p.W) ? off + t * (p.W * opix) : OOB, 0, 0);
+    } else if constexpr (POST == 2) {
+      int x0, x1, y0, y1;
+      float ly;
+      wsr_bil_src(min(st.c0 + fr, p.W - 1), p.Wl, x0, x1, p_lx);
+      wsr_bil_src(st.r, p.Hl, y0, y1, ly);
+      e_r = st.r; e_b = y0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int row = min(y0 + k, p.Hl - 1);
+        const int off = ((st.n * p.Hl + row) * p.Wl) * opix + (cbase + fq * 4) * 2;
+        pv[2 * k] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, off + x0 * opix, 0, 0);
+        pv[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, off + x1 * opix, 0, 0);
+      }
+    }
+  };
+  // POST = 2: the horizontal half of the interpolation once per half-size row (three rows serve the step's output rows)
+  float hrow[POST == 2 ? 3 : 1][4];
+  auto epi_prepare = [&]() __attribute__((always_inline)) {
+    if constexpr (POST == 2) {
+      const float hx = 1.f - p_lx;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int sh = (e & 1) * 16;
+          const float fa = Elem<T>::unpack((pv[2 * k][e >> 1] >> sh) & 0xffffu), fb = Elem<T>::unpack((pv[2 * k + 1][e >> 1] >> sh) & 0xffffu);
+          hrow[k][e] = hx * fa + p_lx * fb;
+        }
+    }
+  };
   auto epi_row = [&](auto tt) __attribute__((always_inline)) {
     constexpr int t = decltype(tt)::value;
     float v[4];
@@ -234,6 +299,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
     for (int e = 0; e < 4; ++e) {
       v[e] = eacc[t][e] + bias[e];
       if constexpr (RELU) v[e] = fmaxf(v[e], 0.f);
+    }
+    if constexpr (POST == 1) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        v[2 * e] += Elem<T>::unpack(pv[t][e] & 0xffffu);
+        v[2 * e + 1] += Elem<T>::unpack(pv[t][e] >> 16);
+      }
+    } else if constexpr (POST == 2) {
+      int y0, y1;
+      float ly;
+      wsr_bil_src(e_r + t, p.Hl, y0, y1, ly);     // wave-uniform
+      const int i = y0 - e_b, j = y1 - e_b;        // 0 / 1 and 0 / 1 / 2: rows of hrow
+      const float hy = 1.f - ly;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float top = i == 0 ? hrow[0][e] : hrow[1][e];
+        const float bot = j == 0 ? hrow[0][e] : (j == 1 ? hrow[1][e] : hrow[2][e]);
+        v[e] += hy * top + ly * bot;               // ATen's order: hy * (hx * a + lx * b) + ly * (hx * c + lx * d)
+      }
     }
     const bool ok = t < e_rows && e_col < p.W;
     const u32x2 pk = {Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3])};
@@ -285,7 +369,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
 #pragma unroll
         for (int t = 0; t < RP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if (had_prev) static_for<0, RP>([&](auto tt) { epi_row(tt); });
+      if (had_prev) { epi_prepare(); static_for<0, RP>([&](auto tt) { epi_row(tt); }); }
+      if constexpr (POST != 0) {          // the storing waves fetch THIS step's post values into the registers the epilogue above
+        asm volatile("" ::: "memory");    // has just consumed; they are used one iteration later (a whole MFMA phase of latency cover)
+        if (KS == 1 || h == KS - 1) post_issue(st);
+      }
       __builtin_amdgcn_sched_barrier(0);
 
       // fragment f = (channel block cbl, input row q, column tap dx): input row r - 1 + q feeds output row r + t with kernel row q - t
@@ -329,15 +417,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
     } else {
       if (fetch_inl && dma_wave) static_for<0, NJ>([&](auto jj) { issue_piece(st_i, jj); });
       asm volatile("" ::: "memory");
-      if (had_prev) static_for<0, RP>([&](auto tt) { epi_row(tt); });
+      if (had_prev) { epi_prepare(); static_for<0, RP>([&](auto tt) { epi_row(tt); }); }
       have_prev = false;
     }
     DP_STAMP(2)
     // the rows fetched in this iteration have landed (they are older than this iteration's stores; with two K parts a wave
     // either fetches or stores)
-    if (KS == 1 && had_prev) wsr_wait_vm<RP>();
+    // (the youngest vector-memory operations of a storing wave are its RP stores and, behind them, its NPL post loads)
+    constexpr bool computes_post = POST != 0;
+    const int npl = (computes_post && sw >= 0 && sw < nst && (KS == 1 || h == KS - 1)) ? NPL : 0;
+    if (KS == 1 && had_prev) { if (npl) wsr_wait_vm<RP + NPL>(); else wsr_wait_vm<RP>(); }
     else if (dma_wave) wsr_wait_vm<0>();
-    else if (fetch_all) { if (had_prev) wsr_wait_vm<RP>(); else wsr_wait_vm<0>(); }
+    else if (fetch_all) {
+      if (had_prev) { if (npl) wsr_wait_vm<RP + NPL>(); else wsr_wait_vm<RP>(); }
+      else { if (npl) wsr_wait_vm<NPL>(); else wsr_wait_vm<0>(); }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     DP_STAMP(3)
     __builtin_amdgcn_s_barrier();
@@ -346,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
     st_w[0] = st_i;
     advance(st_i);
   }
-  if (have_prev) static_for<0, RP>([&](auto tt) { epi_row(tt); });
+  if (have_prev) { epi_prepare(); static_for<0, RP>([&](auto tt) { epi_row(tt); }); }
   if constexpr (DP_EXP & 16) {
     if (lane == 0 && p.dbg) {
 #pragma unroll
@@ -357,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
 #undef DP_STAMP
 }
 
-template <typename T, int C, int RP, bool RELU>
+template <typename T, int C, int RP, bool RELU, int POST>
 int launch_wsr_r(WsrArgs a, hipStream_t stream) {
   constexpr int KS = C / 128, NG = 8 / KS, CS = NG * 16;
   constexpr int ROWB = (18 * (2 * C + 32) + 1023) / 1024 * 1024, NSLOT = (KS + 1) * RP + 4;
@@ -366,7 +460,7 @@ int launch_wsr_r(WsrArgs a, hipStream_t stream) {
   static bool attr_set = false;
   static int cus = 0;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wsr_kernel<T, C, RP, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wsr_kernel<T, C, RP, RELU, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     cus = ws_num_cus();
     attr_set = true;
   }
@@ -385,7 +479,7 @@ int launch_wsr_r(WsrArgs a, hipStream_t stream) {
   a.dbg = dbg;
   (void)hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 8 * 8 * nblk, stream);
 #endif
-  hipLaunchKernelGGL((conv3x3_wsr_kernel<T, C, RP, RELU>), dim3(a.n_pg * a.n_slices), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((conv3x3_wsr_kernel<T, C, RP, RELU, POST>), dim3(a.n_pg * a.n_slices), dim3(512), lds, stream, a);
 #if DP_EXP & 16
   {
     static int shown = 0;
@@ -407,8 +501,13 @@ int launch_wsr_r(WsrArgs a, hipStream_t stream) {
 }
 
 template <typename T, int C, int RP>
-int launch_wsr(const WsrArgs& a, hipStream_t stream) {
-  return a.relu ? launch_wsr_r<T, C, RP, true>(a, stream) : launch_wsr_r<T, C, RP, false>(a, stream);
+int launch_wsr(const WsrArgs& a, hipStream_t stream, int post_mode) {
+  if constexpr (C == 256) {      // the decoder's level sum (256 channels, ReLU heads): the only caller of the post modes
+    if (post_mode == 1 && a.relu) return launch_wsr_r<T, C, RP, true, 1>(a, stream);
+    if (post_mode == 2 && a.relu) return launch_wsr_r<T, C, RP, true, 2>(a, stream);
+  }
+  if (post_mode != 0) return dp_fail(DP_ERR_UNSUPPORTED, "conv3x3_wsr_kernel: post_res needs 256 channels and ReLU");
+  return a.relu ? launch_wsr_r<T, C, RP, true, 0>(a, stream) : launch_wsr_r<T, C, RP, false, 0>(a, stream);
 }
 
 constexpr int kWsrRP128 = 4, kWsrRP256 = 3;
@@ -426,7 +525,9 @@ bool dp_conv_wsr_ok(const dp_conv_params* p) {
   return (p->dtype == DP_BF16 || p->dtype == DP_F16) && shape && p->ntaps == 9 && p->Kpad == 9 * p->Cin && p->stride == 1 &&
          (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == -1 && p->wi_off == -1 && p->H == p->Ho && p->W == p->Wo &&
          !p->residual && !p->out_f32 && !p->head_out && p->out && p->osW == p->Cout && p->osH == (long long)p->W * p->Cout &&
-         p->osN == (long long)p->H * p->W * p->Cout && p->H >= 2 * rp && M >= 2048 && M * 2 * p->Cin < (1ll << 31);
+         p->osN == (long long)p->H * p->W * p->Cout && p->H >= 2 * rp && M >= 2048 && M * 2 * p->Cin < (1ll << 31) &&
+         (p->post_res == nullptr ? p->post_mode == 0
+                                 : (p->Cin == 256 && p->relu && (p->post_mode == 1 || (p->post_mode == 2 && p->H % 2 == 0 && p->W % 2 == 0))));
 }
 
 int dp_conv_wsr_launch(const dp_conv_params* p, dp_stream_t stream) {
@@ -435,6 +536,9 @@ int dp_conv_wsr_launch(const dp_conv_params* p, dp_stream_t stream) {
   a.N = p->N; a.H = p->H; a.W = p->W; a.relu = p->relu; a.kpad = p->Kpad; a.cout = p->Cout;
   a.n_strips = a.spc = a.n_slices = a.n_pg = a.S = 0;
   a.dbg = nullptr;
+  a.post = p->post_res;
+  a.Hl = p->H / 2; a.Wl = p->W / 2;
+  a.post_bytes = p->post_res ? (unsigned)((long long)p->N * (p->post_mode == 2 ? (long long)a.Hl * a.Wl : (long long)p->H * p->W) * p->Cout * 2) : 0u;
   {
     // A launch that has the chip to itself: one persistent workgroup per CU. One that runs beside another stream's launches
     // (dp_conv_params.shared_chip): two workgroups per CU slot, each with half the steps - a static split over exactly as many
@@ -448,6 +552,7 @@ int dp_conv_wsr_launch(const dp_conv_params* p, dp_stream_t stream) {
   a.in_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cin * 2);
   a.out_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cout * 2);
   hipStream_t s = as_stream(stream);
-  if (p->Cin == 128) return p->dtype == DP_BF16 ? launch_wsr<uint16_t, 128, kWsrRP128>(a, s) : launch_wsr<f16_t, 128, kWsrRP128>(a, s);
-  return p->dtype == DP_BF16 ? launch_wsr<uint16_t, 256, kWsrRP256>(a, s) : launch_wsr<f16_t, 256, kWsrRP256>(a, s);
+  const int pm = p->post_res ? p->post_mode : 0;
+  if (p->Cin == 128) return p->dtype == DP_BF16 ? launch_wsr<uint16_t, 128, kWsrRP128>(a, s, pm) : launch_wsr<f16_t, 128, kWsrRP128>(a, s, pm);
+  return p->dtype == DP_BF16 ? launch_wsr<uint16_t, 256, kWsrRP256>(a, s, pm) : launch_wsr<f16_t, 256, kWsrRP256>(a, s, pm);
 }

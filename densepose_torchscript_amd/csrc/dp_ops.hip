@@ -180,11 +180,13 @@ constexpr int kIuvMaxRowFloats = 56 * 96;  // Ws * in_c of the largest supported
 
 __global__ __launch_bounds__(256) void iuv_upsample_split_kernel(const float* __restrict__ in, int R, int Hs, int Ws, int in_c, int n_coarse,
                                                                  int n_fine, float* __restrict__ coarse, float* __restrict__ fine,
-                                                                 float* __restrict__ u, float* __restrict__ v, int xslots) {
+                                                                 float* __restrict__ u, float* __restrict__ v, int xslots,
+                                                                 const int* __restrict__ r_dev) {
   // LDS image: [2 rows][in_c][Ws + 1] - channel-major, so that the lanes of the interpolation loop (consecutive x of one
   // channel) read consecutive words (pixel-major staging put them in_c words apart: in_c = 80 -> 8-way bank conflicts)
   extern __shared__ __attribute__((aligned(16))) float rows[];
   const int r = blockIdx.y;
+  if (r_dev != nullptr && r >= *r_dev) return;  // a box slot behind the live ones (dp_iuv_params.r_dev)
   const int i = (int)blockIdx.x - 1;            // source row pair (i, i+1), i in [-1, Hs-1]
   const int y0 = i < 0 ? 0 : i;
   const int y1 = i + 1 > Hs - 1 ? Hs - 1 : i + 1;
@@ -301,8 +303,9 @@ __global__ __launch_bounds__(kBlock) void merge_up2x_kernel(const T* __restrict_
 // ---- K17: GroupNorm(+ReLU) per ROI, NHWC slice; one workgroup per (roi, group) ------------------------------
 template <typename T>
 __global__ void groupnorm_kernel(T* __restrict__ x, int HW, int C, int c_stride, int c_off, int groups, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float eps, int relu) {
+                                 const float* __restrict__ beta, float eps, int relu, const int* __restrict__ r_dev) {
   const int r = blockIdx.x / groups, g = blockIdx.x % groups;
+  if (r_dev != nullptr && r >= *r_dev) return;
   const int cg = C / groups;
   T* base = x + (long long)r * HW * c_stride + c_off + g * cg;
   const int n = HW * cg;
@@ -340,9 +343,10 @@ __global__ void groupnorm_kernel(T* __restrict__ x, int HW, int C, int c_stride,
 }
 
 template <typename T>
-__global__ void gap_kernel(const T* __restrict__ in, T* __restrict__ out, int HW, int C) {
+__global__ void gap_kernel(const T* __restrict__ in, T* __restrict__ out, int HW, int C, const int* __restrict__ r_dev) {
   // one workgroup per roi; thread t owns channels t, t+256, ... ; sequential sum over pixels (fixed order)
   const int r = blockIdx.x;
+  if (r_dev != nullptr && r >= *r_dev) return;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s = 0.f;
     const T* p = in + (long long)r * HW * C + c;
@@ -352,8 +356,10 @@ __global__ void gap_kernel(const T* __restrict__ in, T* __restrict__ out, int HW
 }
 
 template <typename T>
-__global__ void broadcast_hw_kernel(const T* __restrict__ in, T* __restrict__ out, int R, int HW, int C, int ocs, int oco) {
+__global__ void broadcast_hw_kernel(const T* __restrict__ in, T* __restrict__ out, int R, int HW, int C, int ocs, int oco,
+                                    const int* __restrict__ r_dev) {
   const int C4 = C >> 2;
+  if (r_dev != nullptr) R = min(R, *r_dev);
   const long long total = (long long)R * HW * C4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % C4);
@@ -361,6 +367,18 @@ __global__ void broadcast_hw_kernel(const T* __restrict__ in, T* __restrict__ ou
     const int r = (int)(t / HW);
     store4(out + t * ocs + oco + c4 * 4, load4(in + (long long)r * C + c4 * 4));
   }
+}
+
+// exclusive prefix sum of the per-image detection counts (n_img is a batch size: one thread walks it)
+__global__ void count_offsets_kernel(const int* __restrict__ counts, int n, int* __restrict__ offsets, int* __restrict__ total) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int s = 0;
+  for (int i = 0; i < n; ++i) {
+    offsets[i] = s;
+    const int c = counts[i];
+    s += c > 0 ? c : 0;
+  }
+  total[0] = s;
 }
 
 }  // namespace
@@ -437,8 +455,14 @@ extern "C" int dp_iuv_upsample_split(const dp_iuv_params* p, dp_stream_t stream)
   int xslots = 64;   // power of two >= the output width: a channel lane covers whole waves
   while (xslots < 2 * p->Ws) xslots *= 2;
   hipLaunchKernelGGL(iuv_upsample_split_kernel, dim3(p->Hs + 1, p->R), dim3(256), lds, as_stream(stream), p->in, p->R, p->Hs, p->Ws,
-                     p->in_c, p->n_coarse, p->n_fine, p->coarse, p->fine, p->u, p->v, xslots);
+                     p->in_c, p->n_coarse, p->n_fine, p->coarse, p->fine, p->u, p->v, xslots, p->r_dev);
   return dp_check_launch("iuv_upsample_split_kernel");
+}
+
+extern "C" int dp_count_offsets(const int32_t* counts, int n_img, int32_t* offsets, int32_t* total, dp_stream_t stream) {
+  DP_REQUIRE(counts && offsets && total && n_img > 0, "dp_count_offsets: bad args");
+  hipLaunchKernelGGL(count_offsets_kernel, dim3(1), dim3(64), 0, as_stream(stream), counts, n_img, offsets, total);
+  return dp_check_launch("count_offsets_kernel");
 }
 
 extern "C" int dp_merge_upsample2x_nhwc(const void* base, const void* const* ups, int n_ups, void* out, int N, int H, int W, int C,
@@ -464,27 +488,27 @@ extern "C" int dp_groupnorm_relu_nhwc(const dp_groupnorm_params* p, dp_stream_t 
   hipStream_t s = as_stream(stream);
   const dim3 g(p->R * p->groups), b(kBlock);
   DISPATCH_DTYPE(p->dtype,
-                 hipLaunchKernelGGL(groupnorm_kernel<T>, g, b, 0, s, (T*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu));
+                 hipLaunchKernelGGL(groupnorm_kernel<T>, g, b, 0, s, (T*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu, p->r_dev));
   return dp_check_launch("groupnorm_kernel");
 }
 
-extern "C" int dp_global_avgpool_nhwc(const void* in, void* out, int R, int HW, int C, int dtype, dp_stream_t stream) {
+extern "C" int dp_global_avgpool_nhwc(const void* in, void* out, int R, int HW, int C, int dtype, const int32_t* r_dev, dp_stream_t stream) {
   if (R == 0) return DP_OK;
   DP_REQUIRE(in && out && R > 0 && HW > 0 && C > 0, "dp_global_avgpool_nhwc: bad args");
   hipStream_t s = as_stream(stream);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(gap_kernel<T>, dim3(R), dim3(kBlock), 0, s, (const T*)in, (T*)out, HW, C));
+                 hipLaunchKernelGGL(gap_kernel<T>, dim3(R), dim3(kBlock), 0, s, (const T*)in, (T*)out, HW, C, r_dev));
   return dp_check_launch("gap_kernel");
 }
 
 extern "C" int dp_broadcast_hw_nhwc(const void* in, void* out, int R, int HW, int C, int out_c_stride, int out_c_off, int dtype,
-                                    dp_stream_t stream) {
+                                    const int32_t* r_dev, dp_stream_t stream) {
   if (R == 0) return DP_OK;
   DP_REQUIRE(in && out && R > 0 && HW > 0 && C > 0 && C % 4 == 0 && out_c_off % 4 == 0 && out_c_off + C <= out_c_stride,
              "dp_broadcast_hw_nhwc: bad args");
   const long long total = (long long)R * HW * (C / 4);
   hipStream_t s = as_stream(stream);
   DISPATCH_DTYPE(dtype,
-                 hipLaunchKernelGGL(broadcast_hw_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const T*)in, (T*)out, R, HW, C, out_c_stride, out_c_off));
+                 hipLaunchKernelGGL(broadcast_hw_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, (const T*)in, (T*)out, R, HW, C, out_c_stride, out_c_off, r_dev));
   return dp_check_launch("broadcast_hw_kernel");
 }

@@ -90,6 +90,7 @@ class Engine:
         self.fuse_rpn_head = True     # RPN 3x3 conv + 1x1 heads in one launch where the 256-cout ring kernel runs the level
         self.fuse_bottleneck = True   # res2 blocks: conv2 -> conv3 -> next conv1 in one launch (bottleneck_tail)
         self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
+        self.decoder_fold = True      # 16-bit modes: the decoder's level sum in the conv epilogues (post_res) instead of a merge pass
         self._shared_chip = False     # the launches being issued run beside other large launches (hint to dp_conv2d_nhwc)
         self._side_streams = {}
         self._graphs = {}
@@ -141,11 +142,13 @@ class Engine:
         return torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
 
     def conv(self, layer, x, relu=False, residual=None, rshift=0, out_f32=False, out=None, out_c_stride=None, out_c_off=0,
-             out_geom=None, out_hw=None, head=None):
+             out_geom=None, out_hw=None, head=None, post=None, post_mode=0, n_dev=None):
         """x: Act. Returns Act. out_geom: (osN, osH, osW, base_elems) override for the sub-pixel deconv; out_hw: (Ho, Wo)
         override (the paired-pixel stem, whose input is narrower than its output is wide). head: (weight [16, Cout], bias [16],
         macs per pixel) of a fused 1x1 head on this layer's ReLU output - the call then returns the HEAD's fp32 output
-        [N, Ho, Wo, 16] and the hidden tensor is never written (caller checks head_fusable first)."""
+        [N, Ho, Wo, 16] and the hidden tensor is never written (caller checks head_fusable first). post / post_mode: an Act added
+        AFTER the activation (dp_conv_params.post_res: 1 = same geometry, 2 = half-size map through a bilinear x2; caller checks
+        post_fusable first). n_dev: int32 device tensor [1] = how many of the x.N images hold data (dp_conv_params.n_dev)."""
         p = L.ConvParams()
         N, H, W = x.N, x.H, x.W
         assert x.C == layer.cin, (layer.name, x.C, layer.cin)
@@ -193,6 +196,11 @@ class Engine:
         p.out_f32 = 1 if out_f32 else 0
         p.hi_off, p.wi_off = layer.hi_off, layer.wi_off
         p.shared_chip = 1 if self._shared_chip else 0
+        if n_dev is not None:
+            p.n_dev = n_dev.data_ptr()
+        if post is not None:
+            assert post.C == layer.cout and post.N == N and (post.H, post.W) == ((Ho, Wo) if post_mode == 1 else (Ho // 2, Wo // 2))
+            p.post_res, p.post_mode = post.t.data_ptr(), post_mode
         flops = 2 * (layer.macs_per_pixel + (head[2] if head is not None else 0)) * N * Ho * Wo
         if self.prof is not None and N * Ho * Wo > 0:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -203,12 +211,14 @@ class Engine:
             if cls.startswith("conv_ring_kernel<"):   # one template instance (= one rocprofv3 kernel name) per tile height
                 cls = "conv_ring_kernel<%dx%s" % (self.lib.dp_conv2d_tile_rows(C.byref(p)), cls.split("x")[1])
             if cls == "conv3x3_wsr_kernel":           # ... and per (channels, ReLU) for the weight-stationary kernel
-                cls = "conv3x3_wsr_kernel<%d,%s>" % (x.C, "relu" if relu else "linear")
+                cls = "conv3x3_wsr_kernel<%d,%s%s>" % (x.C, "relu" if relu else "linear", ",post%d" % post_mode if post is not None else "")
             es = x.t.element_size()
             nbytes = (N * (H * W if s == 1 else Ho * Wo * min(layer.ntaps, s * s)) * x.C * es + layer.weight.numel() * es
                       + N * Ho * Wo * layer.cout * (es_out + (es if residual is not None else 0) // (4 if rshift else 1)))
             if head is not None:   # the hidden tensor is never written; the head's 16 fp32 channels are
                 nbytes += N * Ho * Wo * (16 * 4 - layer.cout * es_out)
+            if post is not None:
+                nbytes += post.t.numel() * es
             self.prof.append((cls, flops, e0, e1, "%s%s %dx%dx%d->%d t%d" % (layer.name, "+head" if head is not None else "", Ho, Wo, x.C,
                                                                              layer.cout, layer.ntaps), nbytes))
         else:
@@ -254,6 +264,21 @@ class Engine:
         p.hi_off, p.wi_off = layer.hi_off, layer.wi_off
         p.osN, p.osH, p.osW = x.H * x.W * layer.cout, x.W * layer.cout, layer.cout
         return self.lib.dp_conv2d_kernel_class(C.byref(p)) == 2
+
+    def post_fusable(self, layer, x, post_mode):
+        """True when dp_conv2d_nhwc can add a tensor after this layer's ReLU for input x (dp_conv_params.post_res: the
+        weight-stationary 3x3 kernel, 256 channels, 16-bit storage; mode 2 needs even H and W)."""
+        if self.dt == L.DP_F32 or layer.stride != 1 or (post_mode == 2 and (x.H % 2 or x.W % 2)):
+            return False
+        p = L.ConvParams()
+        p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout = x.N, x.H, x.W, x.C, x.H, x.W, layer.cout
+        p.Cout_w, p.Kpad, p.stride, p.ntaps, p.dtype, p.relu = layer.cout_w, layer.kpad, 1, layer.ntaps, self.dt, 1
+        p.hi_off, p.wi_off = layer.hi_off, layer.wi_off
+        p.osN, p.osH, p.osW = x.H * x.W * layer.cout, x.W * layer.cout, layer.cout
+        p.out = 1                      # placeholders: only NULL / non-NULL matters to the class query
+        p.post_res, p.post_mode = 1, post_mode
+        p.shared_chip = 1 if self._shared_chip else 0
+        return self.lib.dp_conv2d_kernel_class(C.byref(p)) == 6
 
     def bottleneck_tail(self, l2, l3, l1n, t1, residual):
         """conv2 -> conv3 (+ residual, ReLU) -> conv1 of the next block in one launch (dp_bottleneck_tail_nhwc).
@@ -504,6 +529,40 @@ class Engine:
         """roi_head.py:71-79: x = head(p2) + head(p3) + head(p4) + head(p5), each head ending in a bilinear x2 except p2's;
         the three final upsamples and the level sum run as ONE pass (dp_merge_upsample2x_nhwc, same fp32 summation order)."""
         Ls = self.model.layers
+        layout = decoder_layout(self.cfg)
+        # 16-bit modes: the level sum rides in the epilogues of the convolutions that produce its terms. Bilinear up-sampling
+        # is linear, so  x = head2 + up(h3) + up(h4) + up(h5) = head2 + up(h3 + h4 + h5):  the last convolution of every low head adds
+        # the running sum of the heads before it after its ReLU (post_mode 1), and the p2 head adds up(sum) after ITS ReLU
+        # (post_mode 2, taps computed in the kernel). The 756 MB pass of dp_merge_upsample2x_nhwc and its launch disappear;
+        # fp32 parity mode keeps the reference's order (head by head, roi_head.py:76-78) with the merge kernel below.
+        import os as _os
+        fold = (self.decoder_fold and _os.environ.get("DP_DECODER_FOLD", "1") != "0"
+                and all(self.post_fusable(Ls["roi_heads.decoder.%s.%d" % (lvl, 2 * (nconv - 1))],
+                                          # asked for ONE image: the decision must not depend on the batch size (a frame's
+                                          # result is the same whatever else is in the batch), and what fits N = 1 fits any N
+                                          Act(None, 1, feats["p2"].H // (1 if lvl == "p2" else 2), feats["p2"].W // (1 if lvl == "p2" else 2), feats["p2"].C),
+                                          2 if lvl == "p2" else 1) for lvl, nconv in layout)
+                and all(feats[lvl].H * (1 << (nconv - 1)) * 2 == feats["p2"].H and feats[lvl].W * (1 << (nconv - 1)) * 2 == feats["p2"].W
+                        for lvl, nconv in layout if lvl != "p2"))
+        if fold:
+            low_sum = None
+            for lvl, nconv in layout:
+                if lvl == "p2":
+                    continue
+                t = feats[lvl]
+                for k in range(nconv):
+                    last = k == nconv - 1
+                    t = self.conv(Ls["roi_heads.decoder.%s.%d" % (lvl, 2 * k)], t, relu=True,
+                                  post=low_sum if last else None, post_mode=1 if (last and low_sum is not None) else 0)
+                    if not last:
+                        up = self._empty((t.N, 2 * t.H, 2 * t.W, t.C))
+                        L.check(self.lib.dp_upsample_bilinear2x_nhwc(t.t.data_ptr(), up.data_ptr(), t.N, t.H, t.W, t.C, 0, self.dt,
+                                                                     self._stream()), "upsample")
+                        t = Act(up, t.N, 2 * t.H, 2 * t.W, t.C)
+                low_sum = t
+            base = self.conv(Ls["roi_heads.decoder.p2.0"], feats["p2"], relu=True, post=low_sum, post_mode=2)
+            return self.conv(Ls["decoder_predictor"], base)
+
         def scale_head(lvl, nconv):
             t = feats[lvl]
             for k in range(nconv):
@@ -517,7 +576,6 @@ class Engine:
 
         # the scale heads are independent until the level sum: the three small ones run beside the p2 head
         base, lows = None, []
-        layout = decoder_layout(self.cfg)
         for bi, (lvl, nconv) in enumerate(l for l in layout if l[0] != "p2"):
             with self._branch(bi, 4):
                 lows.append(scale_head(lvl, nconv))
@@ -532,39 +590,42 @@ class Engine:
                                                   base.C, self.dt, self._stream()), "dp_merge_upsample2x_nhwc")
         return self.conv(Ls["decoder_predictor"], base)
 
-    def groupnorm(self, x_t, R, HW, Cc, c_stride, c_off, gn, relu=True):
+    def groupnorm(self, x_t, R, HW, Cc, c_stride, c_off, gn, relu=True, r_dev=None):
         p = L.GroupNormParams()
+        p.r_dev = r_dev.data_ptr() if r_dev is not None else None
         p.x, p.R, p.HW, p.C, p.c_stride, p.c_off, p.groups = x_t.data_ptr(), R, HW, Cc, c_stride, c_off, 32
         p.gamma, p.beta, p.eps, p.relu, p.dtype = gn[0].data_ptr(), gn[1].data_ptr(), 1e-5, 1 if relu else 0, self.dt
         L.check(self.lib.dp_groupnorm_relu_nhwc(C.byref(p), self._stream()), "dp_groupnorm_relu_nhwc")
 
-    def dp_head(self, x):
+    def dp_head(self, x, r_dev=None):
+        """x: [R slots, P, P, C]; r_dev: int32 device tensor [1] = how many of the slots hold a box (None: all)."""
         cfg = self.cfg
         Ls = self.model.layers
         R, P = x.N, x.H
+        rp = r_dev.data_ptr() if r_dev is not None else None
         if cfg.is_deeplab:
             gn = self.model.gn
             Cc = x.C
             cat = self._empty((R, P, P, 5 * Cc))
             for i in range(4):
-                self.conv(Ls["aspp%d" % i], x, out=cat, out_c_stride=5 * Cc, out_c_off=i * Cc)
-                self.groupnorm(cat, R, P * P, Cc, 5 * Cc, i * Cc, gn["aspp%d" % i])
+                self.conv(Ls["aspp%d" % i], x, out=cat, out_c_stride=5 * Cc, out_c_off=i * Cc, n_dev=r_dev)
+                self.groupnorm(cat, R, P * P, Cc, 5 * Cc, i * Cc, gn["aspp%d" % i], r_dev=r_dev)
             pooled = self._empty((R, 1, 1, Cc))
-            L.check(self.lib.dp_global_avgpool_nhwc(x.t.data_ptr(), pooled.data_ptr(), R, P * P, Cc, self.dt, self._stream()), "gap")
-            t = self.conv(Ls["aspp4"], Act(pooled, R, 1, 1, Cc))
-            self.groupnorm(t.t, R, 1, Cc, Cc, 0, gn["aspp4"])
-            L.check(self.lib.dp_broadcast_hw_nhwc(t.t.data_ptr(), cat.data_ptr(), R, P * P, Cc, 5 * Cc, 4 * Cc, self.dt, self._stream()),
+            L.check(self.lib.dp_global_avgpool_nhwc(x.t.data_ptr(), pooled.data_ptr(), R, P * P, Cc, self.dt, rp, self._stream()), "gap")
+            t = self.conv(Ls["aspp4"], Act(pooled, R, 1, 1, Cc), n_dev=r_dev)
+            self.groupnorm(t.t, R, 1, Cc, Cc, 0, gn["aspp4"], r_dev=r_dev)
+            L.check(self.lib.dp_broadcast_hw_nhwc(t.t.data_ptr(), cat.data_ptr(), R, P * P, Cc, 5 * Cc, 4 * Cc, self.dt, rp, self._stream()),
                     "broadcast")
-            x = self.conv(Ls["aspp_project"], Act(cat, R, P, P, 5 * Cc), relu=True)
+            x = self.conv(Ls["aspp_project"], Act(cat, R, P, P, 5 * Cc), relu=True, n_dev=r_dev)
         for i in range(cfg.dp_num_convs):
             if cfg.is_deeplab:
-                x = self.conv(Ls["dp_fcn%d" % (i + 1)], x)
-                self.groupnorm(x.t, R, P * P, x.C, x.C, 0, self.model.gn["dp_fcn%d" % (i + 1)])
+                x = self.conv(Ls["dp_fcn%d" % (i + 1)], x, n_dev=r_dev)
+                self.groupnorm(x.t, R, P * P, x.C, x.C, 0, self.model.gn["dp_fcn%d" % (i + 1)], r_dev=r_dev)
             else:
-                x = self.conv(Ls["dp_fcn%d" % (i + 1)], x, relu=True)
+                x = self.conv(Ls["dp_fcn%d" % (i + 1)], x, relu=True, n_dev=r_dev)
         return x
 
-    def dp_predictor(self, x):
+    def dp_predictor(self, x, r_dev=None):
         cfg = self.cfg
         R, P = x.N, x.H
         Ci = self.model.iuv_c
@@ -573,7 +634,7 @@ class Engine:
         for (a, b), layer in self.model.deconv.items():
             # sub-pixel scatter: output pixel (2i + a, 2j + b)
             self.conv(layer, x, out_f32=True, out=low, out_c_stride=Ci,
-                      out_geom=(P2 * P2 * Ci, 2 * P2 * Ci, 2 * Ci, (a * P2 + b) * Ci))
+                      out_geom=(P2 * P2 * Ci, 2 * P2 * Ci, 2 * Ci, (a * P2 + b) * Ci), n_dev=r_dev)
         S = 2 * P2
         nc, nf = cfg.dp_coarse_ch, cfg.dp_patches + 1
         coarse = self._empty((R, nc, S, S), torch.float32)
@@ -583,17 +644,21 @@ class Engine:
         p = L.IuvParams()
         p.in_, p.R, p.Hs, p.Ws, p.in_c, p.n_coarse, p.n_fine = low.data_ptr(), R, P2, P2, Ci, nc, nf
         p.coarse, p.fine, p.u, p.v = coarse.data_ptr(), fine.data_ptr(), u.data_ptr(), v.data_ptr()
+        p.r_dev = r_dev.data_ptr() if r_dev is not None else None
         L.check(self.lib.dp_iuv_upsample_split(C.byref(p), self._stream()), "dp_iuv_upsample_split")
         return coarse, fine, u, v
 
-    def densepose_branch(self, feats, det_boxes, det_counts_dev, counts_host, dec=None):
+    def densepose_branch(self, feats, det_boxes, det_counts_dev, dec=None):
+        """roi_head.py:126-158 for ALL detection slots of the batch, sized on the DEVICE: the launches cover n x D box slots and
+        read the live count R = sum(det_counts) from device memory (dp_count_offsets -> dp_conv_params.n_dev / r_dev), so the host
+        never waits for R in the middle of a step. Returns tensors with n x D rows (the first R live) + the offsets tensor."""
         cfg = self.cfg
         n = feats["p2"].N
         D = det_boxes.shape[1]
-        R = int(sum(counts_host))
-        offs = np.zeros((n,), dtype=np.int32)
-        offs[1:] = np.cumsum(counts_host)[:-1]
-        offsets = torch.from_numpy(offs).to(self.device, non_blocking=True)
+        Rmax = n * D
+        offsets = self._empty((n,), torch.int32)
+        total = self._empty((1,), torch.int32)
+        L.check(self.lib.dp_count_offsets(det_counts_dev.data_ptr(), n, offsets.data_ptr(), total.data_ptr(), self._stream()), "dp_count_offsets")
         if cfg.dp_decoder_on:
             if dec is None:
                 with self._stage("decoder"):
@@ -605,23 +670,18 @@ class Engine:
             maps, scales = [feats[k] for k in ("p2", "p3", "p4", "p5")], [1.0 / s for s in FPN_STRIDES[:4]]
         P = cfg.dp_pool
         Cc = maps[0].C
-        pooled = self._empty((max(R, 1), P, P, Cc))
-        if R > 0:
-            with self._stage("dp_pool"):
-                self.roi_align(maps, scales, det_boxes, det_counts_dev, n, D, P, cfg.dp_sampling, pooled, compact=True, offsets=offsets)
-        x = Act(pooled[:R], R, P, P, Cc)
-        if R == 0:
-            S = 4 * P
-            z = lambda c: torch.zeros((0, c, S, S), dtype=torch.float32, device=self.device)  # noqa: E731
-            return z(cfg.dp_coarse_ch), z(cfg.dp_patches + 1), z(cfg.dp_patches + 1), z(cfg.dp_patches + 1), offs
+        pooled = self._empty((Rmax, P, P, Cc))
+        with self._stage("dp_pool"):
+            self.roi_align(maps, scales, det_boxes, det_counts_dev, n, D, P, cfg.dp_sampling, pooled, compact=True, offsets=offsets)
+        x = Act(pooled, Rmax, P, P, Cc)
         with self._stage("dp_head"):
-            head = self.dp_head(x)
+            head = self.dp_head(x, total)
         if self.keep_intermediates:
             self.inter["dp_pooled"] = x
             self.inter["dp_head_out"] = head
         with self._stage("dp_predictor"):
-            coarse, fine, u, v = self.dp_predictor(head)
-        return coarse, fine, u, v, offs
+            coarse, fine, u, v = self.dp_predictor(head, total)
+        return coarse, fine, u, v
 
     # ------------------------------------------------------------------ whole path for a batch of equal-size frames
     def _phase_a(self, images_u8, given_boxes=None):
@@ -681,7 +741,7 @@ class Engine:
             pinned.copy_(st["det_counts"], non_blocking=True)
         else:
             # everything that changes the captured launch sequence is part of the key
-            key = (tuple(images_u8.shape), slot, self.overlap_decoder, self.fuse_bottleneck, self.fuse_rpn_head, self.fuse_stem_pool, self.fork_levels, self.nms_reference)
+            key = (tuple(images_u8.shape), slot, self.overlap_decoder, self.fuse_bottleneck, self.fuse_rpn_head, self.fuse_stem_pool, self.fork_levels, self.nms_reference, self.decoder_fold)
             entry = self._graphs.pop(key, None)
             if entry is None:
                 # every (stream slot / pipeline lane) of one geometry needs a graph of its own: never cap below the slots in use,
@@ -726,9 +786,9 @@ class Engine:
         # the returned `scores` are slices of this tensor: with graph replay st[...] lives in the graph's memory pool and is
         # overwritten by the next replay, so the results get their own copy (n x D floats)
         det_scores = det_scores.clone()
-        st["counts_event"].synchronize()
-        counts_host = st["counts_pinned"].numpy().astype(np.int64)
-        coarse, fine, u, v, offs = self.densepose_branch(st["feats"], det_boxes, det_counts, counts_host, st.get("dec"))
+        flops0 = self.flops_last
+        coarse, fine, u, v = self.densepose_branch(st["feats"], det_boxes, det_counts, st.get("dec"))
+        flops_dp = self.flops_last - flops0
         # detector_postprocess (postprocessing.py:43-54); image_size there is [W_pad, H_pad] (Q1) minus the padding
         D = det_boxes.shape[1]
         meta = np.zeros((n, 4), dtype=np.float32)
@@ -742,6 +802,18 @@ class Engine:
         p.boxes, p.counts, p.n_img, p.max_dets = det_boxes.data_ptr(), det_counts.data_ptr(), n, D
         p.scale_xy, p.out_hw, p.out_boxes, p.keep = scale_d.data_ptr(), hw_d.data_ptr(), fin_boxes.data_ptr(), keep.data_ptr()
         L.check(self.lib.dp_postprocess_boxes(C.byref(p), self._stream()), "dp_postprocess_boxes")
+        # Everything of the step is enqueued; only now does the host need R - to cut the result views (postprocessing.py:52-61
+        # returns [R, ...] tensors). The device does not wait for this read-back any more.
+        st["counts_event"].synchronize()
+        counts_host = st["counts_pinned"].numpy().astype(np.int64)
+        offs = np.zeros((n,), dtype=np.int64)
+        offs[1:] = np.cumsum(counts_host)[:-1]
+        R = int(counts_host.sum())
+        self.flops_last = flops0 + (flops_dp * R) // max(n * D, 1)     # the launches cover n x D slots, R of them do work
+        if self.keep_intermediates:
+            for k in ("dp_pooled", "dp_head_out"):
+                a = self.inter[k]
+                self.inter[k] = Act(a.t[:R], R, a.H, a.W, a.C)
         results = []
         classes = torch.zeros((n, D), dtype=torch.int64, device=self.device)   # single class: person (fast_rcnn.py:128)
         for i in range(n):

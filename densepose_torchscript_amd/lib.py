@@ -37,7 +37,7 @@ class ConvParams(C.Structure):
                 ("rshift", c_i32), ("relu", c_i32), ("dtype", c_i32), ("out_f32", c_i32),
                 ("hi_off", c_i32), ("wi_off", c_i32), ("stride_w", c_i32),
                 ("head_w", c_void_p), ("head_b", c_void_p), ("head_out", c_void_p),
-                ("shared_chip", c_i32), ("reserved_", c_i32)]
+                ("shared_chip", c_i32), ("post_mode", c_i32), ("post_res", c_void_p), ("n_dev", c_void_p)]
 
 
 class BottleneckParams(C.Structure):
@@ -96,12 +96,13 @@ class PostprocessParams(C.Structure):
 class IuvParams(C.Structure):
     _fields_ = [("in_", c_void_p), ("R", c_i32), ("Hs", c_i32), ("Ws", c_i32), ("in_c", c_i32),
                 ("n_coarse", c_i32), ("n_fine", c_i32),
-                ("coarse", c_void_p), ("fine", c_void_p), ("u", c_void_p), ("v", c_void_p)]
+                ("coarse", c_void_p), ("fine", c_void_p), ("u", c_void_p), ("v", c_void_p), ("r_dev", c_void_p)]
 
 
 class GroupNormParams(C.Structure):
     _fields_ = [("x", c_void_p), ("R", c_i32), ("HW", c_i32), ("C", c_i32), ("c_stride", c_i32), ("c_off", c_i32),
-                ("groups", c_i32), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("relu", c_i32), ("dtype", c_i32)]
+                ("groups", c_i32), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("relu", c_i32), ("dtype", c_i32),
+                ("r_dev", c_void_p)]
 
 
 class ResizeParams(C.Structure):
@@ -150,8 +151,9 @@ SYMBOLS = {
     "dp_postprocess_boxes": (c_int, [C.POINTER(PostprocessParams), c_void_p]),
     "dp_iuv_upsample_split": (c_int, [C.POINTER(IuvParams), c_void_p]),
     "dp_groupnorm_relu_nhwc": (c_int, [C.POINTER(GroupNormParams), c_void_p]),
-    "dp_global_avgpool_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "dp_broadcast_hw_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dp_global_avgpool_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dp_broadcast_hw_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dp_count_offsets": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "dp_fold_frozen_bn": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "dp_conv_taps": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dp_pack_conv_info": (c_int, [C.POINTER(PackParams), C.POINTER(PackInfo)]),

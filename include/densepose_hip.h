@@ -102,7 +102,20 @@ typedef struct {
    * held by another stream (a one-per-CU split cannot, and loses its advantage over the tiled kernels). The result is
    * bit-identical either way. */
   int32_t shared_chip;
-  int32_t reserved_;
+  /* A tensor added AFTER the activation: out = act(conv + bias) + post (weight-stationary 3x3 kernel only, i.e. kernel class 6;
+   * DP_ERR_UNSUPPORTED elsewhere). The DensePose decoder (roi_head.py:71-79) sums its four scale heads after their ReLUs:
+   *   post_mode 1: post_res is a tensor of the OUTPUT's geometry [N, H, W, Cout] (the running sum of the low-resolution heads),
+   *   post_mode 2: post_res is [N, H / 2, W / 2, Cout] and is added through the bilinear x2 up-sampling (align_corners = False)
+   *                the heads end in (roi_head.py:63): out = relu(conv(p2)) + up2(sum of the low heads), H and W even.
+   * Both in fp32 before the one rounding to the storage type. */
+  int32_t post_mode;
+  const void* post_res;
+  /* Device-side image count: when non-NULL, only the first *n_dev of the N images hold data and tiles that start behind them are
+   * skipped (N keeps sizing the launch and the tensors). The DensePose head runs on R detected boxes (roi_head.py:126-158); R is
+   * known on the device only - sizing its launches on the host costs a device -> host round trip in the middle of every step.
+   * Rows behind *n_dev inside the last live tile are computed on whatever the input holds: every image (ROI) is independent,
+   * their outputs are never read. */
+  const int32_t* n_dev;
 } dp_conv_params;
 int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
 /* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile,
@@ -275,6 +288,7 @@ typedef struct {
   const float* in; int32_t R, Hs, Ws, in_c;
   int32_t n_coarse, n_fine;   /* 2|15, 25 */
   float* coarse; float* fine; float* u; float* v;  /* [R][C][2Hs][2Ws] */
+  const int32_t* r_dev;       /* when non-NULL: only the first *r_dev of the R boxes are processed (see dp_conv_params.n_dev) */
 } dp_iuv_params;
 int dp_iuv_upsample_split(const dp_iuv_params* p, dp_stream_t stream);
 
@@ -286,11 +300,16 @@ typedef struct {
   void* x;               /* in/out [R][HW][c_stride] dtype, channels [c_off, c_off + C) */
   int32_t R, HW, C, c_stride, c_off, groups;
   const float* gamma; const float* beta; float eps; int32_t relu; int32_t dtype;
+  const int32_t* r_dev;  /* when non-NULL: only the first *r_dev of the R boxes are processed (see dp_conv_params.n_dev) */
 } dp_groupnorm_params;
 int dp_groupnorm_relu_nhwc(const dp_groupnorm_params* p, dp_stream_t stream);
-int dp_global_avgpool_nhwc(const void* in, void* out, int R, int HW, int C, int dtype, dp_stream_t stream);
+/* r_dev (may be NULL): device-side count of live boxes, as above */
+int dp_global_avgpool_nhwc(const void* in, void* out, int R, int HW, int C, int dtype, const int32_t* r_dev, dp_stream_t stream);
 int dp_broadcast_hw_nhwc(const void* in, void* out, int R, int HW, int C, int out_c_stride, int out_c_off, int dtype,
-                         dp_stream_t stream);
+                         const int32_t* r_dev, dp_stream_t stream);
+/* exclusive prefix sum of the per-image detection counts (fast_rcnn.py:86-140 keeps at most max_dets per image): offsets[i] = the
+ * first row of image i in the compact ROI list, total[0] = R. One tiny launch instead of a read-back + host cumsum + upload. */
+int dp_count_offsets(const int32_t* counts, int n_img, int32_t* offsets, int32_t* total, dp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Host-side weight pipeline (CPU code, no stream): canonical fp32 parameters -> the packed operands of

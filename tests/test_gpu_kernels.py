@@ -486,6 +486,47 @@ def test_conv3x3_weight_stationary_equals_ring_kernel(eng, dt, shape, monkeypatc
     assert bool(((gd - ref).abs() <= ulp * ref.abs() + 2e-3).all()), float((gd - ref).abs().max())
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("shape", [(1, 50, 84), (2, 24, 46), (3, 30, 26), (1, 100, 168), (8, 14, 22)])
+def test_conv3x3_post_activation_sum(eng, dt, mode, shape):
+    """dp_conv_params.post_res (the decoder's level sum in the conv epilogue, roi_head.py:71-79): out = relu(conv(x) + b) + post
+    (mode 1, same geometry) and out = relu(conv(x) + b) + bilinear_x2(post) (mode 2, half-size map, align_corners=False) on the
+    weight-stationary 3x3 kernel, against torch in fp64 - ragged heights / strip widths, several images, more workgroups than
+    steps; exact up to the one rounding to the storage type."""
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    e = eng[dt]
+    N, H, W = shape
+    Cc = 256
+    g = torch.Generator().manual_seed(1000 * mode + H * W + N)
+    x = _round(torch.randn((N, Cc, H, W), generator=g), dt)
+    w = _round(torch.randn((Cc, Cc, 3, 3), generator=g) * (2.0 / (Cc * 9)) ** 0.5, dt)
+    b = torch.randn((Cc,), generator=g) * 0.1
+    hp, wp = (H, W) if mode == 1 else (H // 2, W // 2)
+    post = _round(torch.randn((N, Cc, hp, wp), generator=g), dt)
+    layer = conv_from_oihw("t", w.numpy(), b.numpy(), Cc, 1, 1, 1, e.dt, e.device)
+    xa = Act(_nhwc(x, Cc, e.tdt, e.device), N, H, W, Cc)
+    pa = Act(_nhwc(post, Cc, e.tdt, e.device), N, hp, wp, Cc)
+    assert e.post_fusable(layer, xa, mode)
+    got = e.conv(layer, xa, relu=True, post=pa, post_mode=mode)
+    plain = e.conv(layer, xa, relu=True)
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
+    ref = ref + (post.double() if mode == 1 else F.interpolate(post.double(), scale_factor=2.0, mode="bilinear", align_corners=False))
+    gd = got.t.float().cpu().permute(0, 3, 1, 2).double()
+    ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    assert bool(((gd - ref).abs() <= ulp * ref.abs() + 2e-4).all()), float((gd - ref).abs().max())
+    # ... and the conv part is the plain launch's: subtracting the post term in fp64 leaves relu(conv) up to the two roundings
+    pd = plain.t.float().cpu().permute(0, 3, 1, 2).double()
+    add = post.double() if mode == 1 else F.interpolate(post.double(), scale_factor=2.0, mode="bilinear", align_corners=False)
+    assert bool(((gd - add - pd).abs() <= ulp * (ref.abs() + pd.abs()) + 2e-4).all())
+    # unsupported combinations are refused, not ignored
+    from densepose_torchscript_amd import lib as L
+    with pytest.raises(L.DensePoseHipError):
+        e.conv(layer, xa, relu=False, post=pa, post_mode=mode)
+
+
 def test_conv_fpn_lateral_plus_nearest_upsample(eng):
     from densepose_torchscript_amd.engine import Act
     from densepose_torchscript_amd.pack import conv_from_oihw
@@ -824,10 +865,10 @@ def test_box_decode_and_groupnorm_gap(eng):
     assert float(buf[..., :Cc].abs().max()) == 0.0
     xin = x.permute(0, 2, 3, 1).contiguous().to(dev)
     pooled = torch.empty((Rr, Cc), device=dev)
-    assert e.lib.dp_global_avgpool_nhwc(xin.data_ptr(), pooled.data_ptr(), Rr, HW, Cc, L.DP_F32, e._stream()) == 0
+    assert e.lib.dp_global_avgpool_nhwc(xin.data_ptr(), pooled.data_ptr(), Rr, HW, Cc, L.DP_F32, None, e._stream()) == 0
     assert torch.allclose(pooled.cpu(), x.mean(dim=(2, 3)), atol=1e-5)
     bc = torch.zeros((Rr, HW, 2 * Cc), device=dev)
-    assert e.lib.dp_broadcast_hw_nhwc(pooled.data_ptr(), bc.data_ptr(), Rr, HW, Cc, 2 * Cc, Cc, L.DP_F32, e._stream()) == 0
+    assert e.lib.dp_broadcast_hw_nhwc(pooled.data_ptr(), bc.data_ptr(), Rr, HW, Cc, 2 * Cc, Cc, L.DP_F32, None, e._stream()) == 0
     assert torch.equal(bc[..., Cc:].cpu(), pooled.cpu()[:, None, :].expand(Rr, HW, Cc))
 
 
@@ -861,11 +902,11 @@ def test_groupnorm_gap_broadcast_all_dtypes(eng, dt, shape):
     assert other.numel() == 0 or float(other.float().abs().max()) == 0.0       # channels outside the slice are untouched
     xin = x.permute(0, 2, 3, 1).contiguous().to(e.tdt).to(e.device)
     pooled = torch.empty((Rr, Cc), dtype=e.tdt, device=e.device)
-    assert e.lib.dp_global_avgpool_nhwc(xin.data_ptr(), pooled.data_ptr(), Rr, HW, Cc, e.dt, e._stream()) == 0
+    assert e.lib.dp_global_avgpool_nhwc(xin.data_ptr(), pooled.data_ptr(), Rr, HW, Cc, e.dt, None, e._stream()) == 0
     mref = x.double().mean(dim=(2, 3))
     assert bool(((pooled.double().cpu() - mref).abs() <= ulp * mref.abs() + 1e-5).all())
     bc = torch.zeros((Rr, HW, cstride), dtype=e.tdt, device=e.device)
-    assert e.lib.dp_broadcast_hw_nhwc(pooled.data_ptr(), bc.data_ptr(), Rr, HW, Cc, cstride, coff, e.dt, e._stream()) == 0
+    assert e.lib.dp_broadcast_hw_nhwc(pooled.data_ptr(), bc.data_ptr(), Rr, HW, Cc, cstride, coff, e.dt, None, e._stream()) == 0
     assert torch.equal(bc[..., coff:coff + Cc].cpu(), pooled.cpu()[:, None, :].expand(Rr, HW, Cc))
 
 
