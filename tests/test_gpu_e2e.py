@@ -44,7 +44,7 @@ def _assert_rows_match(boxes, scores, ref_boxes, ref_scores, score_tol=1e-4, box
 TINY = ["tiny_r50_s1x_a", "tiny_r50_s1x_b", "tiny_r50_legacy", "tiny_r101_s1x", "tiny_r50_dl", "tiny_r101_dl"]
 
 
-@pytest.mark.parametrize("name", TINY + ["full_r50_s1x_small", "full_r50_s1x_800x1333", "full_r50_dl_p28", "tiny_r101_dl_p28_video"])
+@pytest.mark.parametrize("name", TINY + ["full_r50_s1x_small", "full_r101_s1x_small", "full_r50_s1x_800x1333", "full_r50_dl_p28", "tiny_r101_dl_p28_video"])
 def test_fp32_matches_reference_golden(name):
     from oracle.ref_cpu import extract_iuv
     meta, z, cfg, pred, out = _run(name, "fp32", keep=True)
@@ -93,7 +93,7 @@ def test_fp32_matches_reference_golden(name):
         assert np.abs(got - ref).max() <= 5e-4 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("name", ["tiny_r50_s1x_a", "tiny_r50_legacy", "tiny_r50_dl", "full_r50_s1x_small", "full_r50_s1x_800x1333"])
+@pytest.mark.parametrize("name", ["tiny_r50_s1x_a", "tiny_r50_legacy", "tiny_r50_dl", "full_r50_s1x_small", "full_r101_s1x_small", "full_r50_s1x_800x1333"])
 def test_fp32_matches_cpu_oracle_live(name):
     """Same seeded inputs through the oracle on the host and the HIP path on the GPU: every pixel of the full-resolution
     IUV maps (the goldens of the full-width cases store a subsample), full channel width included - the BASELINE.json

@@ -7,7 +7,7 @@ from conftest import golden_case_inputs, load_golden
 from oracle.ref_cpu import OracleModel, extract_iuv
 
 CPU_CASES = ["tiny_r50_s1x_a", "tiny_r50_s1x_b", "tiny_r50_legacy", "tiny_r101_s1x", "tiny_r50_dl", "tiny_r101_dl",
-             "full_r50_s1x_small", "full_r50_dl_p28", "tiny_r101_dl_p28_video"]
+             "full_r50_s1x_small", "full_r101_s1x_small", "full_r50_dl_p28", "tiny_r101_dl_p28_video"]
 
 
 @pytest.mark.parametrize("name", CPU_CASES)
