@@ -42,8 +42,10 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ src, T* __restrict
   }
 }
 
-// paired layout (dp_preprocess_params.paired): cell j of a row holds the 4-channel pixels 2j - 3 and 2j - 2
-template <typename T>
+// paired layout (dp_preprocess_params.paired): cell j of a row holds the 4-channel pixels 2j - 3 and 2j - 2.
+// HWC = the source frames are interleaved [n][h][w][3] (a frame as the caller hands it over, defaults.py:76-78) instead of the
+// planar [n][3][h][w] output of the resize: at scale 1 the resize is the identity and the frames are read directly.
+template <typename T, bool HWC>
 __global__ void preprocess_paired_kernel(const uint8_t* __restrict__ src, T* __restrict__ dst, int n_img, int h, int w, int Hp,
                                          int Wq, float m0, float m1, float m2, float s0, float s1, float s2) {
   const long long total = (long long)n_img * Hp * Wq;
@@ -58,10 +60,17 @@ __global__ void preprocess_paired_kernel(const uint8_t* __restrict__ src, T* __r
       const int x = 2 * j + e - 3;
       px[e] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (y < h && x >= 0 && x < w) {
-        const uint8_t* s = src + ((long long)n * 3 * h + y) * w + x;
-        px[e].x = ((float)s[0] - m0) / s0;
-        px[e].y = ((float)s[(long long)h * w] - m1) / s1;
-        px[e].z = ((float)s[2ll * h * w] - m2) / s2;
+        int v0, v1, v2;
+        if constexpr (HWC) {
+          const uint8_t* s = src + (((long long)n * h + y) * w + x) * 3;
+          v0 = s[0]; v1 = s[1]; v2 = s[2];
+        } else {
+          const uint8_t* s = src + ((long long)n * 3 * h + y) * w + x;
+          v0 = s[0]; v1 = s[(long long)h * w]; v2 = s[2ll * h * w];
+        }
+        px[e].x = ((float)v0 - m0) / s0;
+        px[e].y = ((float)v1 - m1) / s1;
+        px[e].z = ((float)v2 - m2) / s2;
       }
     }
     T* d = dst + i * 8;
@@ -398,11 +407,18 @@ extern "C" int dp_preprocess_u8(const dp_preprocess_params* p, dp_stream_t strea
     DP_REQUIRE(p->Wp % 2 == 0, "dp_preprocess_u8: the paired layout needs an even padded width");
     const int Wq = p->Wp / 2 + 3;
     const long long cells = (long long)p->n_img * p->Hp * Wq;
-    DISPATCH_DTYPE(p->dtype,
-                   hipLaunchKernelGGL(preprocess_paired_kernel<T>, dim3(grid_for(cells)), dim3(kBlock), 0, s, p->src, (T*)p->dst,
-                                      p->n_img, p->h, p->w, p->Hp, Wq, p->mean[0], p->mean[1], p->mean[2], p->std[0], p->std[1], p->std[2]));
+    if (p->src_hwc) {
+      DISPATCH_DTYPE(p->dtype,
+                     hipLaunchKernelGGL((preprocess_paired_kernel<T, true>), dim3(grid_for(cells)), dim3(kBlock), 0, s, p->src, (T*)p->dst,
+                                        p->n_img, p->h, p->w, p->Hp, Wq, p->mean[0], p->mean[1], p->mean[2], p->std[0], p->std[1], p->std[2]));
+    } else {
+      DISPATCH_DTYPE(p->dtype,
+                     hipLaunchKernelGGL((preprocess_paired_kernel<T, false>), dim3(grid_for(cells)), dim3(kBlock), 0, s, p->src, (T*)p->dst,
+                                        p->n_img, p->h, p->w, p->Hp, Wq, p->mean[0], p->mean[1], p->mean[2], p->std[0], p->std[1], p->std[2]));
+    }
     return dp_check_launch("preprocess_paired_kernel");
   }
+  DP_REQUIRE(!p->src_hwc, "dp_preprocess_u8: interleaved (HWC) source frames need the paired layout");
   const long long total = (long long)p->n_img * p->Hp * p->Wp;
   DISPATCH_DTYPE(p->dtype,
                  hipLaunchKernelGGL(preprocess_kernel<T>, dim3(grid_for(total)), dim3(kBlock), 0, s, p->src, (T*)p->dst,

@@ -22,7 +22,7 @@ c_void_p, c_int, c_i32, c_i64, c_float = C.c_void_p, C.c_int, C.c_int32, C.c_int
 class PreprocessParams(C.Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p),
                 ("n_img", c_i32), ("h", c_i32), ("w", c_i32), ("Hp", c_i32), ("Wp", c_i32), ("dtype", c_i32),
-                ("mean", c_float * 3), ("inv_std_unused", c_float * 3), ("std", c_float * 3), ("paired", c_i32)]
+                ("mean", c_float * 3), ("inv_std_unused", c_float * 3), ("std", c_float * 3), ("paired", c_i32), ("src_hwc", c_i32)]
 
 
 class ConvParams(C.Structure):

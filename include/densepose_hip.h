@@ -57,6 +57,9 @@ typedef struct {
                             right by 3 pixels, TWO pixels per 8-channel cell - cell j holds pixels 2j - 3 and 2j - 2. The 7x7
                             stride-2 stem (resnet.py:350-353) then is a 7 x 4-tap convolution with stride (2, 1) over cells:
                             K = 7 * 4 * 8 = 224 instead of 49 * 8 = 392 (3 of 8 channels used -> 6 of 8). */
+  int32_t src_hwc;    /* 1 (paired layout only): src is [n_img][h][w][3], the frames as the caller hands them over (defaults.py:76-78).
+                         At scale 1 - a frame that already has the test size - the uint8 resize of defaults.py:89 is the identity, and
+                         the two resize passes + the planar intermediate are skipped. */
 } dp_preprocess_params;
 int dp_preprocess_u8(const dp_preprocess_params* p, dp_stream_t stream);
 

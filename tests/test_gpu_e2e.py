@@ -534,3 +534,29 @@ def test_fused_launches_equal_layer_by_layer_end_to_end(dtype, monkeypatch):
     for w, g in zip(want, got):
         for k in w:
             assert torch.equal(w[k], g[k].cpu()), (dtype, k)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_frames_of_the_test_size_skip_the_resize(dtype):
+    """A frame whose shortest edge already is MIN_SIZE_TEST has scale 1 (defaults.py:84-89): the uint8 resize is the identity and
+    the engine reads the frames as handed over (interleaved HWC, dp_preprocess_params.src_hwc) - device frames, host frames,
+    with and without graphs; the results equal the reference-exact host resize path bit for bit."""
+    from densepose_torchscript_amd import TINY_OPTS, get_config, make_synthetic_state
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    cfg = get_config("densepose_rcnn_R_50_FPN_s1x", TINY_OPTS + ["INPUT.MIN_SIZE_TEST", 96, "INPUT.MAX_SIZE_TEST", 160])
+    state = make_synthetic_state(cfg, 5)
+    rng = np.random.default_rng(31)
+    imgs = [torch.from_numpy(rng.integers(0, 256, (96, 160, 3), dtype=np.uint8)) for _ in range(4)]
+    host = DensePosePredictor(cfg, state, dtype=dtype, resize="host")
+    assert host._scale(96, 160) == 1.0
+    want = [{k: v.cpu() for k, v in r.items()} for r in host.predict_batch(imgs)]
+    for graphs in (False, True):
+        dev = DensePosePredictor(cfg, state, dtype=dtype, resize="device", use_graphs=graphs, pipeline_depth=2 if graphs else 1)
+        for frames in ([im.cuda() for im in imgs], imgs, [im.permute(2, 0, 1).contiguous().cuda() for im in imgs]):
+            for rep in range(2):
+                got = dev.predict_batch(frames)
+            dev.join()
+            torch.cuda.synchronize()
+            for w_, g_ in zip(want, got):
+                for k in w_:
+                    assert torch.equal(w_[k], g_[k].cpu()), (dtype, graphs, k)

@@ -334,6 +334,14 @@ def test_paired_preprocess_and_stem(eng, dt, shape):
     want[:, :, 3:3 + Wp, :3] = xp.permute(0, 2, 3, 1)
     ulp = {"fp32": 0.0, "bf16": 2.0 ** -8, "fp16": 2.0 ** -11}[dt]
     assert bool(((cells - want).abs() <= ulp * want.abs() + 1e-6).all())
+    # the same frames handed over interleaved ([n, h, w, 3], src_hwc): bit-identical buffer (the scale-1 path that skips the resize)
+    buf2 = torch.full((n, Hp, Wq, 8), 9.0, dtype=e.tdt, device=e.device)
+    src2 = img.permute(0, 2, 3, 1).contiguous().to(e.device)
+    p.src, p.dst, p.src_hwc = src2.data_ptr(), buf2.data_ptr(), 1
+    L.check(e.lib.dp_preprocess_u8(C.byref(p), e._stream()), "dp_preprocess_u8")
+    assert torch.equal(buf, buf2)
+    p.paired = 0
+    assert e.lib.dp_preprocess_u8(C.byref(p), e._stream()) == -1      # interleaved frames need the paired layout
     # stem on it
     wt = torch.randn((16, 3, 7, 7), generator=g) * 0.05
     b = torch.randn((16,), generator=g)
