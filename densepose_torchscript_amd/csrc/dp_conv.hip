@@ -53,6 +53,9 @@ struct ConvArgs {
   unsigned in_bytes, w_bytes, res_bytes;   // buffer-resource extents (ring / streaming kernels)
   int ntaps, out_linear, res_linear;
   const int* n_dev;       // device-side count of live images (dp_conv_params.n_dev): tiles that start behind them exit at once
+  const void* in2;        // second source of a pointwise layer (dp_conv_params.in2): K channels >= Cin come from it
+  int H2, W2, Cin2, stride2;
+  unsigned in2_bytes;
   const void* head_w;     // fused 1x1 head (RPN): plain [16][Cout] storage type, rows = head channels
   const float* head_b;    // [16]
   float* head_out;        // [M][16] fp32
@@ -292,6 +295,10 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs 
 //   WC = 2, TP = 4 : 128 pixels x 128 couts, 4 waves (64 x 64 each),               4 x 16 KiB ring, 2 workgroups / CU
 // =====================================================================================================
 constexpr int kRing = 4;
+#ifndef DP_RING_SPREAD_NUM
+#define DP_RING_SPREAD_NUM 1
+#define DP_RING_SPREAD_DEN 1
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -308,7 +315,10 @@ __device__ __forceinline__ void wait_planes(int planes, int pw) {
   else { if (pw == 4) wait_vmcnt<8>(); else wait_vmcnt<6>(); }
 }
 
-template <typename T, int WC, int TP>
+// DUAL: the pointwise layer has a second source (dp_conv_params.in2). A template parameter, not a runtime flag: the extra per-lane
+// offsets, the second buffer resource and the per-plane source select cost the 224- and 256-row instances 21 - 25 % when they are
+// merely PRESENT in the kernel (scalar registers 97 - 100 of 102), measured in round 3.
+template <typename T, int WC, int TP, bool DUAL>
 __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArgs p) {
   constexpr int ES = sizeof(T);
   constexpr int CH = 16 / ES;
@@ -380,18 +390,39 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
   const int w_boff = ((n0 + wave * 32 + srow) * p.Kpad + scc * CH) * ES;
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
+  // Second source of a pointwise layer (the projection shortcut of a bottleneck's first block as extra K planes of its conv3,
+  // resnet.py:189-205: out = relu(W3 t2 + Ws x[::s, ::s] + b)): K channels >= Cin are read from in2 at pixel (ho * stride2,
+  // wo * stride2). The plane's source is wave-uniform (its channel offset comes from the scalar tap table).
+  constexpr bool dual = DUAL;
+  const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dual ? p.in2 : p.in), 0, dual ? p.in2_bytes : 0u, 0x00020000);
+  int a_boff2[2] = {0, 0};
+  if constexpr (dual) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + (wave + i * NW) * 16 + srow;
+      if (m < p.M && (i == 0 || a2)) {
+        const int n = m / p.HoWo;
+        const int rem = m - n * p.HoWo;
+        const int ho = rem / p.Wo;
+        const int wo = rem - ho * p.Wo;
+        a_boff2[i] = (((n * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.Cin2 + scc * CH) * ES;
+      }
+    }
+  }
   unsigned char* const lds_sa = smem + wave * 1024;              // pixel piece `wave` (+ NW*1024: piece wave + NW)
   unsigned char* const lds_sb = smem + A_PLANE + wave * 2048;    // this wave's two weight pieces
 
 #define DP_RING_STAGE(S_IDX, E)                                                                                    \
   {                                                                                                                \
-    const int tap_boff = (((E)[0] * p.W + (E)[1]) * p.Cin + (E)[2]) * ES;                                          \
+    const bool src2_ = dual && (E)[2] >= p.Cin;                                                                    \
+    const int tap_boff = src2_ ? ((E)[2] - p.Cin) * ES : (((E)[0] * p.W + (E)[1]) * p.Cin + (E)[2]) * ES;          \
     const unsigned tapbit = ((E)[3] & 1) ? (1u << ((E)[3] >> 8)) : 0u;                                             \
     const int slot_ = ((S_IDX) & (kRing - 1)) * SLOT;                                                              \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
       if (i == 0 || a2) {                                                                                          \
-        const int off = (a_okm[i] & tapbit) ? (a_boff[i] + tap_boff) : (int)0x80000000;                            \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(lds_sa + slot_ + i * NW * 1024), 16, off, 0, 0, 0); \
+        const int off = (a_okm[i] & tapbit) ? ((src2_ ? a_boff2[i] : a_boff[i]) + tap_boff) : (int)0x80000000;     \
+        if (src2_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, DP_LDS_PTR(lds_sa + slot_ + i * NW * 1024), 16, off, 0, 0, 0); \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(lds_sa + slot_ + i * NW * 1024), 16, off, 0, 0, 0); \
       }                                                                                                            \
     }                                                                                                              \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
@@ -464,24 +495,36 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
     if (a2) wait_vmcnt<4>(); else wait_vmcnt<3>();   // only plane S+2 may still be in flight
     __builtin_amdgcn_s_barrier();
     const i32x4 e = e_nx;
-    const int tap_boff = ((e[0] * p.W + e[1]) * p.Cin + e[2]) * ES;
+    const bool src2 = dual && e[2] >= p.Cin;
+    const int tap_boff = src2 ? (e[2] - p.Cin) * ES : ((e[0] * p.W + e[1]) * p.Cin + e[2]) * ES;
     const unsigned tapbit = (e[3] & 1) ? (1u << (e[3] >> 8)) : 0u;
     const int dslot = ((S + 3) & (kRing - 1)) * SLOT;
     const int rslot = ((S + 1) & (kRing - 1)) * SLOT;
-    e_nx = ktab_c[min(S + 4, ns - 1) * 4];
     static_for<0, N_PAIR>([&](auto pi) {
       constexpr int pr = decltype(pi)::value;
       Mma<T>::run(fc_cur[pr / TP], fp_cur[pr % TP], acc[pr / TP][pr % TP]);
+      if constexpr (pr == 1) {
+        // The scalar load of the NEXT step's tap entry is pinned behind the first MFMAs. Left to the scheduler it sometimes lands
+        // in front of them, directly followed by the s_waitcnt lgkmcnt(0) that guards this step's fragment registers: the wave then
+        // sits out a scalar-cache round trip after every barrier (round 3: the same source compiled to a 128x256 instance 23 %
+        // slower after an unrelated template parameter was added; the ISA differed in exactly this placement).
+        __builtin_amdgcn_sched_barrier(0);
+        e_nx = ktab_c[min(S + 4, ns - 1) * 4];
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // memory instructions spread evenly over the MFMA groups
-      constexpr int m_lo = pr * N_MEM / N_PAIR, m_hi = (pr + 1) * N_MEM / N_PAIR;
+      // (the memory instructions are spread over the first DP_RING_SPREAD_NUM / DP_RING_SPREAD_DEN of the step's MFMA groups)
+      constexpr int NPE = (N_PAIR * DP_RING_SPREAD_NUM + DP_RING_SPREAD_DEN - 1) / DP_RING_SPREAD_DEN;
+      constexpr int m_lo = pr >= NPE ? N_MEM : pr * N_MEM / NPE, m_hi = pr + 1 >= NPE ? N_MEM : (pr + 1) * N_MEM / NPE;
       if constexpr (m_hi > m_lo) {
         __builtin_amdgcn_sched_barrier(0);
         static_for<m_lo, m_hi>([&](auto mi) {
           constexpr int m = decltype(mi)::value;
           if constexpr (m < 2) {
             if (m == 0 || a2) {
-              const int off = (a_okm[m] & tapbit) ? (a_boff[m] + tap_boff) : (int)0x80000000;
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(lds_sa + dslot + m * NW * 1024), 16, off, 0, 0, 0);
+              const int off = (a_okm[m] & tapbit) ? ((src2 ? a_boff2[m] : a_boff[m]) + tap_boff) : (int)0x80000000;
+              if (src2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, DP_LDS_PTR(lds_sa + dslot + m * NW * 1024), 16, off, 0, 0, 0);
+              else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(lds_sa + dslot + m * NW * 1024), 16, off, 0, 0, 0);
             }
           } else if constexpr (m < 4) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DP_LDS_PTR(lds_sb + dslot + (m - 2) * 1024), 16,
@@ -576,17 +619,21 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
 #undef DP_RING_READ
 #undef DP_RING_STEP
 
-template <typename T, int WC, int TP>
-int launch_conv_ring(const ConvArgs& a, hipStream_t stream) {
+template <typename T, int WC, int TP, bool DUAL>
+int launch_conv_ring_d(const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = 2 * TP * 16, BN = WC * 64;
   constexpr int lds = kRing * (BM + BN) * 64;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<T, WC, TP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<T, WC, TP, DUAL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_ring_kernel<T, WC, TP>), dim3(a.n_tiles), dim3(WC * 2 * 64), lds, stream, a);
+  hipLaunchKernelGGL((conv_ring_kernel<T, WC, TP, DUAL>), dim3(a.n_tiles), dim3(WC * 2 * 64), lds, stream, a);
   return dp_check_launch("conv_ring_kernel");
+}
+template <typename T, int WC, int TP>
+int launch_conv_ring(const ConvArgs& a, hipStream_t stream) {
+  return a.in2 ? launch_conv_ring_d<T, WC, TP, true>(a, stream) : launch_conv_ring_d<T, WC, TP, false>(a, stream);
 }
 
 template <typename T, int BN, int NPL>
@@ -975,6 +1022,12 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
                          !p->out_f32 && lin_out && (lin_res || up_res) && M >= 4096 &&
                          // 32-bit buffer offsets, rows up to one grid stride of tiles past the end are addressed
                          (M + (1ll << 16)) * 2 * (p->Cin > p->osW ? p->Cin : (p->osW > p->rsW ? p->osW : p->rsW)) < (1ll << 31);
+  if (p->in2) {   // second source (K-concatenated pointwise layer): the LDS-ring kernels implement it (DP_CONV_BIG=2: the 128x128 one)
+    const char* f2 = getenv("DP_CONV_BIG");
+    if (!ring_ok) return -1;
+    if (big_ok && ((M + 127) / 128) * (p->Cout / 256) >= 128 && !(f2 && atoi(f2) == 2)) return DP_CONV_RING256;
+    return DP_CONV_RING128;
+  }
   const char* fe = getenv("DP_CONV_BIG");  // test/debug knob - 0: generic only, 1: 256x256 ring whenever legal, 2: 128x128 ring whenever legal, 5: streaming 1x1 whenever legal
   if (fe) {
     const int f = atoi(fe);
@@ -1108,10 +1161,22 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   a.ntaps = p->ntaps;
   a.head_w = p->head_w; a.head_b = p->head_b; a.head_out = p->head_out;
   a.n_dev = p->n_dev;
+  a.in2 = p->in2; a.H2 = p->H2; a.W2 = p->W2; a.Cin2 = p->Cin2; a.stride2 = p->stride2;
+  a.in2_bytes = p->in2 ? (unsigned)((long long)p->N * p->H2 * p->W2 * p->Cin2 * es) : 0u;
+  if (p->in2) {
+    DP_REQUIRE(p->ntaps == 1 && p->stride == 1 && p->hi_off == 0 && p->wi_off == 0 && p->H == p->Ho && p->W == p->Wo,
+               "dp_conv2d_nhwc: a second source needs a pointwise stride-1 layer");
+    DP_REQUIRE(p->Cin2 > 0 && (p->Cin * es) % 64 == 0 && (p->Cin2 * es) % 64 == 0 && p->Kpad == p->Cin + p->Cin2,
+               "dp_conv2d_nhwc: second source: Cin=%d Cin2=%d Kpad=%d (both 64-byte multiples, Kpad = their sum)", p->Cin, p->Cin2, p->Kpad);
+    DP_REQUIRE(p->stride2 >= 1 && p->H2 >= (p->Ho - 1) * p->stride2 + 1 && p->W2 >= (p->Wo - 1) * p->stride2 + 1 &&
+               (long long)p->N * p->H2 * p->W2 * p->Cin2 * es < (1ll << 31), "dp_conv2d_nhwc: second source geometry");
+    DP_REQUIRE(!p->head_out, "dp_conv2d_nhwc: second source and fused head are exclusive");
+  }
   a.out_linear = (p->osH == (long long)p->Wo * p->osW && p->osN == (long long)p->Ho * p->osH) ? 1 : 0;
   a.res_linear = (p->residual && p->rshift == 0 && p->rsH == (long long)p->Wo * p->rsW && p->rsN == (long long)p->Ho * p->rsH) ? 1 : 0;
   hipStream_t s = as_stream(stream);
   const int kc = choose_conv_kernel(p, M);
+  if (kc < 0) return dp_fail(DP_ERR_UNSUPPORTED, "dp_conv2d_nhwc: a second source needs a shape the LDS-ring kernels take");
   if (p->head_out) {
     // fused 1x1 head: the 256-cout ring kernel only (all channels of a pixel in one workgroup), 16-bit storage, ReLU hidden layer
     DP_REQUIRE(p->head_w && p->head_b, "dp_conv2d_nhwc: head_out given without head_w / head_b");

@@ -90,6 +90,7 @@ class Engine:
         self.fuse_rpn_head = True     # RPN 3x3 conv + 1x1 heads in one launch where the 256-cout ring kernel runs the level
         self.fuse_bottleneck = True   # res2 blocks: conv2 -> conv3 -> next conv1 in one launch (bottleneck_tail)
         self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
+        self.fuse_shortcut = _os.environ.get("DP_FUSE_SHORTCUT", "1") != "0"   # block-0 projection shortcut as K planes of conv3 (16-bit modes)
         self.decoder_fold = True      # 16-bit modes: the decoder's level sum in the conv epilogues (post_res) instead of a merge pass
         self._shared_chip = False     # the launches being issued run beside other large launches (hint to dp_conv2d_nhwc)
         self._side_streams = {}
@@ -143,16 +144,22 @@ class Engine:
         return torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
 
     def conv(self, layer, x, relu=False, residual=None, rshift=0, out_f32=False, out=None, out_c_stride=None, out_c_off=0,
-             out_geom=None, out_hw=None, head=None, post=None, post_mode=0, n_dev=None):
+             out_geom=None, out_hw=None, head=None, post=None, post_mode=0, n_dev=None, in2=None):
         """x: Act. Returns Act. out_geom: (osN, osH, osW, base_elems) override for the sub-pixel deconv; out_hw: (Ho, Wo)
         override (the paired-pixel stem, whose input is narrower than its output is wide). head: (weight [16, Cout], bias [16],
         macs per pixel) of a fused 1x1 head on this layer's ReLU output - the call then returns the HEAD's fp32 output
         [N, Ho, Wo, 16] and the hidden tensor is never written (caller checks head_fusable first). post / post_mode: an Act added
         AFTER the activation (dp_conv_params.post_res: 1 = same geometry, 2 = half-size map through a bilinear x2; caller checks
-        post_fusable first). n_dev: int32 device tensor [1] = how many of the x.N images hold data (dp_conv_params.n_dev)."""
+        post_fusable first). n_dev: int32 device tensor [1] = how many of the x.N images hold data (dp_conv_params.n_dev).
+        in2: second source Act of a pack.dual_source_pointwise layer (dp_conv_params.in2), read at stride layer.stride2."""
         p = L.ConvParams()
         N, H, W = x.N, x.H, x.W
-        assert x.C == layer.cin, (layer.name, x.C, layer.cin)
+        if in2 is not None:
+            assert x.C == layer.cin1 and in2.C == layer.cin2 and in2.N == N, (layer.name, x.C, in2.C)
+            assert in2.H >= (H - 1) * layer.stride2 + 1 and in2.W >= (W - 1) * layer.stride2 + 1
+            p.in2, p.H2, p.W2, p.Cin2, p.stride2 = in2.t.data_ptr(), in2.H, in2.W, in2.C, layer.stride2
+        else:
+            assert x.C == layer.cin, (layer.name, x.C, layer.cin)
         s = layer.stride
         if s == 1:
             Ho, Wo = H, W
@@ -214,7 +221,9 @@ class Engine:
             if cls == "conv3x3_wsr_kernel":           # ... and per (channels, ReLU) for the weight-stationary kernel
                 cls = "conv3x3_wsr_kernel<%d,%s%s>" % (x.C, "relu" if relu else "linear", ",post%d" % post_mode if post is not None else "")
             es = x.t.element_size()
-            nbytes = (N * (H * W if s == 1 else Ho * Wo * min(layer.ntaps, s * s)) * x.C * es + layer.weight.numel() * es
+            if in2 is not None:
+                nbytes_in2 = N * Ho * Wo * in2.C * es
+            nbytes = ((nbytes_in2 if in2 is not None else 0) + N * (H * W if s == 1 else Ho * Wo * min(layer.ntaps, s * s)) * x.C * es + layer.weight.numel() * es
                       + N * Ho * Wo * layer.cout * (es_out + (es if residual is not None else 0) // (4 if rshift else 1)))
             if head is not None:   # the hidden tensor is never written; the head's 16 fp32 channels are
                 nbytes += N * Ho * Wo * (16 * 4 - layer.cout * es_out)
@@ -370,15 +379,20 @@ class Engine:
         for bi, (stage, b, cin, cmid, cout, stride, sc) in enumerate(blocks):
             p = "%s%s.%d." % (bu, stage, b)
             with self._stage("backbone." + stage):
-                shortcut = self.conv(Ls[p + "shortcut"], x) if sc else x
+                fused_sc = Ls.get(p + "conv3+shortcut") if (sc and self.fuse_shortcut) else None
+                shortcut = x if (not sc or fused_sc is not None) else self.conv(Ls[p + "shortcut"], x)
                 t = t_next if t_next is not None else self.conv(Ls[p + "conv1"], x, relu=True)
                 t_next = None
                 # conv1 of the next block of the SAME stage (stride 1, reads this block's output) rides in the fused tail
                 nxt = blocks[bi + 1] if bi + 1 < len(blocks) and blocks[bi + 1][0] == stage else None
                 l1n = Ls["%s%s.%d.conv1" % (bu, nxt[0], nxt[1])] if nxt is not None else None
-                fused = self.bottleneck_tail(Ls[p + "conv2"], Ls[p + "conv3"], l1n, t, shortcut) if self.fuse_bottleneck else None
+                fused = self.bottleneck_tail(Ls[p + "conv2"], Ls[p + "conv3"], l1n, t, shortcut) if (self.fuse_bottleneck and fused_sc is None) else None
                 if fused is not None:
                     x, t_next = fused
+                elif fused_sc is not None:
+                    # out = relu(W3 t2 + Ws x[::s, ::s] + b3 + bs): the block's input is the second source of conv3's K axis
+                    t = self.conv(Ls[p + "conv2"], t, relu=True)
+                    x = self.conv(fused_sc, t, relu=True, in2=x)
                 else:
                     t = self.conv(Ls[p + "conv2"], t, relu=True)
                     x = self.conv(Ls[p + "conv3"], t, relu=True, residual=shortcut)
@@ -757,7 +771,7 @@ class Engine:
             pinned.copy_(st["det_counts"], non_blocking=True)
         else:
             # everything that changes the captured launch sequence is part of the key
-            key = (shape, hwc, slot, self.overlap_decoder, self.fuse_bottleneck, self.fuse_rpn_head, self.fuse_stem_pool, self.fork_levels, self.nms_reference, self.decoder_fold)
+            key = (shape, hwc, slot, self.overlap_decoder, self.fuse_bottleneck, self.fuse_rpn_head, self.fuse_stem_pool, self.fork_levels, self.nms_reference, self.decoder_fold, self.fuse_shortcut)
             entry = self._graphs.pop(key, None)
             if entry is None:
                 # every (stream slot / pipeline lane) of one geometry needs a graph of its own: never cap below the slots in use,

@@ -37,7 +37,8 @@ class ConvParams(C.Structure):
                 ("rshift", c_i32), ("relu", c_i32), ("dtype", c_i32), ("out_f32", c_i32),
                 ("hi_off", c_i32), ("wi_off", c_i32), ("stride_w", c_i32),
                 ("head_w", c_void_p), ("head_b", c_void_p), ("head_out", c_void_p),
-                ("shared_chip", c_i32), ("post_mode", c_i32), ("post_res", c_void_p), ("n_dev", c_void_p)]
+                ("shared_chip", c_i32), ("post_mode", c_i32), ("post_res", c_void_p), ("n_dev", c_void_p),
+                ("in2", c_void_p), ("H2", c_i32), ("W2", c_i32), ("Cin2", c_i32), ("stride2", c_i32)]
 
 
 class BottleneckParams(C.Structure):

@@ -102,6 +102,27 @@ def conv_from_oihw(name, w, bias, cin_alloc, stride, pad, dil, dtype, device, in
                       plane_major=plane_major)
 
 
+def dual_source_pointwise(name, w1, b1, cin1_alloc, w2, b2, cin2_alloc, stride2, dtype, device):
+    """out = W1 x1 + W2 x2[::stride2, ::stride2] + (b1 + b2) as ONE pointwise layer whose K axis is the cin1 channels of the first
+    source followed by the cin2 channels of the second (dp_conv_params.in2): conv3 of the first bottleneck block of a ResNet stage
+    with the block's projection shortcut as extra K planes (resnet.py:189-205). w1: [Cout, cin1, 1, 1], w2: [Cout, cin2, 1, 1]
+    (FrozenBN already folded). Both channel counts must be multiples of 32 (a 64-byte K plane belongs to one source)."""
+    co, c1 = w1.shape[0], w1.shape[1]
+    c2 = w2.shape[1]
+    es = 4 if dtype == DP_F32 else 2
+    assert w2.shape[0] == co and (cin1_alloc * es) % 64 == 0 and (cin2_alloc * es) % 64 == 0 and c1 <= cin1_alloc and c2 <= cin2_alloc
+    assert ((cin1_alloc + cin2_alloc) * es) % 128 == 0, "the K axis is padded to 128 bytes: the two sources together must fill it"
+    wcat = np.zeros((co, 1, cin1_alloc + cin2_alloc), dtype=np.float32)
+    wcat[:, 0, :c1] = w1.reshape(co, c1)
+    wcat[:, 0, cin1_alloc:cin1_alloc + c2] = w2.reshape(co, c2)
+    layer = PackedConv(name, wcat, [(0, 0)], (np.asarray(b1, np.float32) + np.asarray(b2, np.float32)), cin1_alloc + cin2_alloc, co,
+                       1, 0, 0, dtype, device)
+    assert layer.kpad == cin1_alloc + cin2_alloc
+    layer.cin1, layer.cin2, layer.stride2 = cin1_alloc, cin2_alloc, stride2
+    layer.macs_per_pixel = co * (c1 + c2)
+    return layer
+
+
 def stem_paired_conv(name, w, bias, dtype, device):
     """The 7x7 stride-2 pad-3 stem (resnet.py:350-353) over the PAIRED image layout of dp_preprocess_u8 (paired=1): cell j of a
     row = the 4-channel pixels 2j - 3 and 2j - 2 (3 real channels + 1 zero each). Output column wo reads pixels 2wo - 3 ..
@@ -179,6 +200,12 @@ class PackedModel:
             # 64 -> 64 3x3 in 16-bit storage (the res2 blocks): tap-major K for the fused bottleneck tail
             L[p + "conv2"] = bnconv(p + "conv2", A8(cmid), 1, 1, plane_major=False if (cmid == 64 and dtype != DP_F32) else None)
             L[p + "conv3"] = bnconv(p + "conv3", A8(cmid), 1, 0)
+            # first block of res3 / res4 / res5 in the 16-bit modes: the projection shortcut as extra K planes of conv3 (one launch,
+            # the shortcut tensor is never written or read back; fp32 parity mode keeps the reference's two convolutions + add)
+            if sc and stage != "res2" and dtype != DP_F32 and A8(cmid) % 32 == 0 and A8(cin) % 32 == 0 and (A8(cmid) + A8(cin)) % 64 == 0:
+                w3, s3 = _fold_bn(st[p + "conv3.weight"].astype(np.float32), st, p + "conv3.norm")
+                ws, ss = _fold_bn(st[p + "shortcut.weight"].astype(np.float32), st, p + "shortcut.norm")
+                L[p + "conv3+shortcut"] = dual_source_pointwise(p + "conv3+shortcut", w3, s3, A8(cmid), ws, ss, A8(cin), stride, dtype, device)
         c = cfg.res2_out
         F = A8(cfg.fpn_out)
         for lvl in (2, 3, 4, 5):

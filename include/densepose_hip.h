@@ -119,6 +119,13 @@ typedef struct {
    * Rows behind *n_dev inside the last live tile are computed on whatever the input holds: every image (ROI) is independent,
    * their outputs are never read. */
   const int32_t* n_dev;
+  /* Second source of a pointwise (1 tap, stride 1) layer: K = Cin channels of `in` followed by Cin2 channels of `in2`, an
+   * [N, H2, W2, Cin2] tensor read at pixel (ho * stride2, wo * stride2); Kpad = Cin + Cin2, both multiples of 64 bytes; the
+   * weight matrix is the one of a (Cin + Cin2)-channel 1x1 convolution. The projection shortcut of the first block of a ResNet
+   * stage (resnet.py:189-205: out = relu(conv3(t2) + shortcut(x))) is then part of conv3's K axis - the shortcut tensor is neither
+   * written nor read back. LDS-ring kernels only (DP_ERR_UNSUPPORTED otherwise). */
+  const void* in2;
+  int32_t H2, W2, Cin2, stride2;
 } dp_conv_params;
 int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
 /* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile,

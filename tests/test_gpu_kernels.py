@@ -535,6 +535,40 @@ def test_conv3x3_post_activation_sum(eng, dt, mode, shape):
         e.conv(layer, xa, relu=False, post=pa, post_mode=mode)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("shape", [(2, 128, 256, 512, 25, 42, 2), (1, 256, 512, 1024, 13, 21, 2), (3, 64, 192, 256, 17, 9, 1),
+                                   (8, 128, 256, 512, 50, 84, 2), (1, 512, 1024, 2048, 7, 11, 2)])
+def test_conv_pointwise_two_sources(eng, dt, shape, monkeypatch):
+    """dp_conv_params.in2: out = relu(W1 x1 + W2 x2[::s, ::s] + b) as one pointwise layer whose K axis is x1's channels followed
+    by x2's (conv3 of a stage's first bottleneck block + its projection shortcut, resnet.py:189-205), on both LDS-ring kernels,
+    against torch in fp64."""
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import dual_source_pointwise
+    e = eng[dt]
+    N, c1, c2, co, H, W, s2 = shape
+    g = torch.Generator().manual_seed(c1 + c2 + H * W)
+    x1 = torch.randn((N, c1, H, W), generator=g)
+    H2, W2 = (H - 1) * s2 + 1 + (s2 - 1), (W - 1) * s2 + 1          # a source that is not an exact multiple of the stride
+    x2 = torch.randn((N, c2, H2, W2), generator=g)
+    w1 = torch.randn((co, c1, 1, 1), generator=g) * (1.0 / c1) ** 0.5
+    w2 = torch.randn((co, c2, 1, 1), generator=g) * (1.0 / c2) ** 0.5
+    b1, b2 = torch.randn((co,), generator=g), torch.randn((co,), generator=g)
+    if dt != "fp32":
+        x1, x2, w1, w2 = _round(x1, dt), _round(x2, dt), _round(w1, dt), _round(w2, dt)
+    ref = F.relu(F.conv2d(x1.double(), w1.double(), b1.double()) + F.conv2d(x2.double()[:, :, ::s2, ::s2][:, :, :H, :W], w2.double(), b2.double()))
+    layer = dual_source_pointwise("t", w1.numpy(), b1.numpy(), c1, w2.numpy(), b2.numpy(), c2, s2, e.dt, e.device)
+    a1 = Act(_nhwc(x1, c1, e.tdt, e.device), N, H, W, c1)
+    a2 = Act(_nhwc(x2, c2, e.tdt, e.device), N, H2, W2, c2)
+    for force in (None, "2"):                  # the policy's choice and the 128x128 ring kernel
+        if force:
+            monkeypatch.setenv("DP_CONV_BIG", force)
+        out = e.conv(layer, a1, relu=True, in2=a2, out_f32=True)
+        torch.cuda.synchronize()
+        got = out.t.cpu().permute(0, 3, 1, 2).double()
+        err = (got - ref).abs().max().item()
+        assert err <= 2e-5 * max(ref.abs().max().item(), 1.0) * (c1 + c2) ** 0.5, (shape, force, err)
+
+
 def test_conv_fpn_lateral_plus_nearest_upsample(eng):
     from densepose_torchscript_amd.engine import Act
     from densepose_torchscript_amd.pack import conv_from_oihw
