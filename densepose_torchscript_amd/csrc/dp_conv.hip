@@ -295,10 +295,6 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs 
 //   WC = 2, TP = 4 : 128 pixels x 128 couts, 4 waves (64 x 64 each),               4 x 16 KiB ring, 2 workgroups / CU
 // =====================================================================================================
 constexpr int kRing = 4;
-#ifndef DP_RING_SPREAD_NUM
-#define DP_RING_SPREAD_NUM 1
-#define DP_RING_SPREAD_DEN 1
-#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -513,9 +509,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
         __builtin_amdgcn_sched_barrier(0);
       }
       // memory instructions spread evenly over the MFMA groups
-      // (the memory instructions are spread over the first DP_RING_SPREAD_NUM / DP_RING_SPREAD_DEN of the step's MFMA groups)
-      constexpr int NPE = (N_PAIR * DP_RING_SPREAD_NUM + DP_RING_SPREAD_DEN - 1) / DP_RING_SPREAD_DEN;
-      constexpr int m_lo = pr >= NPE ? N_MEM : pr * N_MEM / NPE, m_hi = pr + 1 >= NPE ? N_MEM : (pr + 1) * N_MEM / NPE;
+      constexpr int m_lo = pr * N_MEM / N_PAIR, m_hi = (pr + 1) * N_MEM / N_PAIR;
       if constexpr (m_hi > m_lo) {
         __builtin_amdgcn_sched_barrier(0);
         static_for<m_lo, m_hi>([&](auto mi) {

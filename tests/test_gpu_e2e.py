@@ -184,6 +184,10 @@ def test_device_resize_equals_host_resize():
 # 0.965 / 0.985 (tiny_r50_s1x_a / full_r50_s1x_small / the 800x1333 headline frame), fp16 1.0 / 0.9988 / 0.9987; the DeepLab cases
 # have tiny boxes (3 - 384 label pixels in all: one flipped pixel is 0.3 - 33 %), bf16 0.67 - 0.95, fp16 0.948 - 0.996
 BF16_LABEL_FLOOR = {"tiny_r50_s1x_a": 0.97, "full_r50_s1x_small": 0.93, "full_r50_dl_p28": 0.5}
+# largest IUV deviation on the matched detections, relative to the largest reference value of the same map (round 3, tools/measure_bands.py):
+# 0.016 / 0.027 on the s1x cases - held to 3x that; the DeepLab head at pool 28 (GroupNorm over 8 / 16-channel groups of random-weight
+# activations, logits of range +-2) measures 0.25 - 0.44 depending on the build's rounding points: a regression guard only
+BF16_IUV_BAND = {"tiny_r50_s1x_a": 0.05, "full_r50_s1x_small": 0.08, "full_r50_dl_p28": 0.6}
 FP16_LABEL_FLOOR = 0.9
 
 
@@ -240,7 +244,7 @@ def _label_agreement(out, z, box_tol):
 def test_bf16_mode_stays_in_its_measured_band(name):
     """Throughput mode (bf16 operands, fp32 accumulate) against the fp32 reference golden: the detections are found (box within
     1.5 px, score within 0.05; at most one borderline detection may come or go) and the IUV maps of the matched detections
-    stay within 40 % of the map's range. BASELINE.json configs[3] (R_50_FPN_DL bf16) = the full_r50_dl_p28 case:
+    stay within the per-case band BF16_IUV_BAND of the map's range. BASELINE.json configs[3] (R_50_FPN_DL bf16) = the full_r50_dl_p28 case:
     bf16 GroupNorm / global average pool / broadcast at the real pool-28 geometry."""
     meta, z, cfg, pred, out = _run(name, "bf16")
     for k in IUV_KEYS:
@@ -249,7 +253,7 @@ def test_bf16_mode_stays_in_its_measured_band(name):
     assert abs(out["scores"].shape[0] - R) <= 1
     hits, iuv = _match_to_reference(out, z, meta["iuv_stride"], 1.5, 0.05)
     assert hits >= R - 1, (hits, R)
-    assert iuv <= 0.4, iuv
+    assert iuv <= BF16_IUV_BAND[name], iuv
     agree, npx = _label_agreement(out, z, 1.5)
     assert npx > 0 and agree >= BF16_LABEL_FLOOR[name], (name, agree)
 
