@@ -295,6 +295,9 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs 
 //   WC = 2, TP = 4 : 128 pixels x 128 couts, 4 waves (64 x 64 each),               4 x 16 KiB ring, 2 workgroups / CU
 // =====================================================================================================
 constexpr int kRing = 4;
+#ifndef DP_RING_EXP
+#define DP_RING_EXP 0     // diagnostic builds: 1 = no LDS-DMA issue in the steady loop, 2 = every piece reads one contiguous (cached) KiB, 4 = weight pieces read the tile a tiled weight layout would give them
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -514,15 +517,24 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
         __builtin_amdgcn_sched_barrier(0);
         static_for<m_lo, m_hi>([&](auto mi) {
           constexpr int m = decltype(mi)::value;
-          if constexpr (m < 2) {
+          if constexpr (DP_RING_EXP & 1) {
+            if constexpr (m >= 4) {     // diagnostic build: no LDS-DMA issue in the steady loop (results are garbage, timing only)
+              if constexpr (m < 4 + TC) fc_nxt[m - 4] = *reinterpret_cast<const u32x4*>(rd_b + rslot + (m - 4) * 16 * 64);
+              else fp_nxt[m - 4 - TC] = *reinterpret_cast<const u32x4*>(rd_a + rslot + (m - 4 - TC) * 16 * 64);
+            }
+          } else if constexpr (m < 2) {
             if (m == 0 || a2) {
-              const int off = (a_okm[m] & tapbit) ? ((src2 ? a_boff2[m] : a_boff[m]) + tap_boff) : (int)0x80000000;
+              int off = (a_okm[m] & tapbit) ? ((src2 ? a_boff2[m] : a_boff[m]) + tap_boff) : (int)0x80000000;
+              if constexpr (DP_RING_EXP & 2) off = lane * 16;     // diagnostic: same instruction count, one contiguous KiB per piece
               if (src2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, DP_LDS_PTR(lds_sa + dslot + m * NW * 1024), 16, off, 0, 0, 0);
               else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(lds_sa + dslot + m * NW * 1024), 16, off, 0, 0, 0);
             }
           } else if constexpr (m < 4) {
+            // (DP_RING_EXP & 4: the access pattern of a weight matrix stored in 1 KiB tiles of 16 rows x 64 B - wrong data, timing only)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DP_LDS_PTR(lds_sb + dslot + (m - 2) * 1024), 16,
-                                                     w_boff + (16 * (m - 2) * p.Kpad + (S + 3) * PE) * ES, 0, 0, 0);
+                                                     (DP_RING_EXP & 2) ? lane * 16 + (m - 2) * 1024
+                                                     : (DP_RING_EXP & 4) ? (((n0 / 16 + wave * 2 + (m - 2)) * (p.Kpad * ES / 64) + (S + 3)) * 1024 + lane * 16)
+                                                     : w_boff + (16 * (m - 2) * p.Kpad + (S + 3) * PE) * ES, 0, 0, 0);
           } else if constexpr (m < 4 + TC) {
             fc_nxt[m - 4] = *reinterpret_cast<const u32x4*>(rd_b + rslot + (m - 4) * 16 * 64);
           } else {

@@ -152,6 +152,23 @@ class Engine:
         AFTER the activation (dp_conv_params.post_res: 1 = same geometry, 2 = half-size map through a bilinear x2; caller checks
         post_fusable first). n_dev: int32 device tensor [1] = how many of the x.N images hold data (dp_conv_params.n_dev).
         in2: second source Act of a pack.dual_source_pointwise layer (dp_conv_params.in2), read at stride layer.stride2."""
+        if (in2 is not None or post is not None) and head is None and out_geom is None and out_c_stride is None and not out_f32:
+            # The kernels behind in2 / post address their tensors with 32-bit byte offsets: a batch whose largest tensor exceeds
+            # 2 GiB (64 frames of 800x1344 at the res3 / p2 levels) goes image chunk by image chunk. Per-pixel arithmetic does not
+            # depend on the chunking (nor on the batch size: the same kernels run either way).
+            es_ = x.t.element_size()
+            per_img = max(x.H * x.W * x.C, x.H * x.W * layer.cout, in2.H * in2.W * in2.C if in2 is not None else 0) * es_
+            per = max(1, ((1 << 31) - 1) // per_img)
+            if per < x.N:
+                sl = lambda a, n0, n: Act(a.t[n0:n0 + n], n, a.H, a.W, a.C)   # noqa: E731
+                if out is None:
+                    out = self._empty((x.N, x.H, x.W, layer.cout))
+                for n0 in range(0, x.N, per):
+                    n = min(per, x.N - n0)
+                    self.conv(layer, sl(x, n0, n), relu=relu, residual=None if residual is None else sl(residual, n0, n), rshift=rshift,
+                              out=out[n0:n0 + n], post=None if post is None else sl(post, n0, n), post_mode=post_mode,
+                              in2=None if in2 is None else sl(in2, n0, n))
+                return Act(out, x.N, x.H, x.W, layer.cout)
         p = L.ConvParams()
         N, H, W = x.N, x.H, x.W
         if in2 is not None:
@@ -218,6 +235,8 @@ class Engine:
             cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_ring_kernel<256x256>", "conv_ring_kernel<128x128>", "conv_ring2_kernel<256x128>", "conv1x1_stream_kernel", "conv3x3_wsr_kernel")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
             if cls.startswith("conv_ring_kernel<"):   # one template instance (= one rocprofv3 kernel name) per tile height
                 cls = "conv_ring_kernel<%dx%s" % (self.lib.dp_conv2d_tile_rows(C.byref(p)), cls.split("x")[1])
+                if in2 is not None:                   # ... and per source count (the two-source form is its own instance)
+                    cls = cls[:-1] + ",2src>"
             if cls == "conv3x3_wsr_kernel":           # ... and per (channels, ReLU) for the weight-stationary kernel
                 cls = "conv3x3_wsr_kernel<%d,%s%s>" % (x.C, "relu" if relu else "linear", ",post%d" % post_mode if post is not None else "")
             es = x.t.element_size()

@@ -148,14 +148,16 @@ def test_batch_equals_single_calls():
             assert torch.equal(single[k].cpu(), b[k].cpu()), k
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_full_width_batch_equals_single_calls_16bit(dtype):
+@pytest.mark.parametrize("dtype,cfgname", [("bf16", "densepose_rcnn_R_50_FPN_s1x"), ("fp16", "densepose_rcnn_R_50_FPN_s1x"),
+                                           ("bf16", "densepose_rcnn_R_50_FPN_DL_s1x"), ("fp16", "densepose_rcnn_R_101_FPN_DL_s1x")])
+def test_full_width_batch_equals_single_calls_16bit(dtype, cfgname):
     """Same property at full channel width in the 16-bit modes, where every conv kernel family is in play (256x256 /
     256x128 / 128x128 ring tiles, streaming 1x1, generic): a frame's result does not depend on what else is in the batch
     (tiles that span two frames, persistent waves that walk across frames), graph replay and pipeline lanes included."""
     from densepose_torchscript_amd import get_config, make_synthetic_state
     from densepose_torchscript_amd.predictor import DensePosePredictor
-    cfg = get_config("densepose_rcnn_R_50_FPN_s1x", ["INPUT.MIN_SIZE_TEST", 256, "INPUT.MAX_SIZE_TEST", 400, "TEST.DETECTIONS_PER_IMAGE", 6])
+    # (the DeepLab variants = BASELINE.json configs[3] / [4]: GroupNorm / pool / broadcast over device-sized ROI counts, R101 trunk)
+    cfg = get_config(cfgname, ["INPUT.MIN_SIZE_TEST", 256, "INPUT.MAX_SIZE_TEST", 400, "TEST.DETECTIONS_PER_IMAGE", 6])
     state = make_synthetic_state(cfg, 3)
     rng = np.random.default_rng(11)
     imgs = [torch.from_numpy(rng.integers(0, 256, (256, 400, 3), dtype=np.uint8)).cuda() for _ in range(6)]
@@ -564,3 +566,25 @@ def test_frames_of_the_test_size_skip_the_resize(dtype):
             for w_, g_ in zip(want, got):
                 for k in w_:
                     assert torch.equal(w_[k], g_[k].cpu()), (dtype, graphs, k)
+
+
+def test_batch_64_full_size_frames_equal_single_calls():
+    """BASELINE.json configs[3] / [4] hand a GPU up to 64 frames: at 800x1333 the res2 / res3 / p2-level tensors of such a batch
+    exceed 2 GiB, so the kernels that address tensors with 32-bit offsets (fused res2 tail, the two-source conv3 + shortcut, the
+    decoder's post-activation sums) run image chunk by image chunk - a frame's result must still be the single-call result."""
+    from densepose_torchscript_amd import get_config, make_synthetic_state
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    cfg = get_config("densepose_rcnn_R_50_FPN_s1x", ["TEST.DETECTIONS_PER_IMAGE", 4])
+    state = make_synthetic_state(cfg, 0)
+    rng = np.random.default_rng(77)
+    base = [torch.from_numpy(rng.integers(0, 256, (800, 1333, 3), dtype=np.uint8)).cuda() for _ in range(4)]
+    frames = [base[i % 4] for i in range(64)]
+    pred = DensePosePredictor(cfg, state, dtype="bf16", resize="device")
+    got = pred.predict_batch(frames)
+    torch.cuda.synchronize()
+    for i in (0, 1, 63):
+        want = pred(frames[i])
+        torch.cuda.synchronize()
+        assert int(want["scores"].shape[0]) > 0
+        for k in want:
+            assert torch.equal(want[k].cpu(), got[i][k].cpu()), (i, k)

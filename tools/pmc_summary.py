@@ -19,7 +19,8 @@ def short(name):
         args = [a.strip() for a in m.group(2).split(",")]
         dt = {"unsigned short": "bf16", "_Float16": "f16", "float": "f32"}.get(args[0], args[0])
         if m.group(1) == "conv_ring_kernel":
-            return "conv_ring_kernel<%dx%d>[%s]" % (32 * int(args[2]), 64 * int(args[1]), dt)
+            two = len(args) > 3 and args[3] in ("true", "1")      # round 3: the two-source form is a template instance of its own
+            return "conv_ring_kernel<%dx%d%s>[%s]" % (32 * int(args[2]), 64 * int(args[1]), ",2src" if two else "", dt)
         if m.group(1) == "conv_ring2_kernel":
             return "conv_ring2_kernel<256x128>[%s]" % dt
         if m.group(1) == "conv1x1_stream_kernel":
@@ -29,7 +30,8 @@ def short(name):
     if m:   # <storage type, channels, rows per step, relu>: the class names engine.py / bench.py use
         args = [a.strip() for a in m.group(1).split(",")]
         dt = {"unsigned short": "bf16", "_Float16": "f16"}.get(args[0], args[0])
-        return "conv3x3_wsr_kernel<%s,%s>[%s]" % (args[1], "relu" if args[3] in ("true", "1") else "linear", dt)
+        post = ",post%s" % args[4] if len(args) > 4 and args[4] not in ("0",) else ""
+        return "conv3x3_wsr_kernel<%s,%s%s>[%s]" % (args[1], "relu" if args[3] in ("true", "1") else "linear", post, dt)
     m = re.search(r"bottleneck_tail64_kernel<([^>]*)>", name)
     if m:
         args = [a.strip() for a in m.group(1).split(",")]
