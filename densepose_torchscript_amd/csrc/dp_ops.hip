@@ -1,6 +1,7 @@
 // Memory-bound NHWC helper kernels of the DensePose path (HBM-bound: coalesced 8/16-byte accesses,
 // grid-stride, no LDS needed except the GroupNorm reduction).
 #include "dp_common.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)  // keep mul/add un-fused: these ops are compared with the CPU oracle
 
@@ -351,6 +352,80 @@ __global__ void groupnorm_kernel(T* __restrict__ x, int HW, int C, int c_stride,
   }
 }
 
+// The same normalisation with the group held in REGISTERS: one 16-byte read and one 16-byte write per 8 (bf16 / fp16) or 4 (fp32)
+// elements instead of three element-wise sweeps over global memory (a 28 x 28 x 16-channel group of the DeepLab head is 25 KB).
+// Two-pass statistics (mean, then centred variance) in fp32 with fixed per-thread order + reduction tree: deterministic.
+// Legal when a 16-byte vector does not straddle groups (cg * sizeof(T) % 16 == 0) and the group fits VPT vectors per thread.
+template <typename T, int VPT>
+__global__ __launch_bounds__(kBlock) void groupnorm_reg_kernel(T* __restrict__ x, int HW, int C, int c_stride, int c_off, int groups,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                              int relu, const int* __restrict__ r_dev) {
+  constexpr int VE = 16 / sizeof(T);            // elements per vector
+  const int r = blockIdx.x / groups, g = blockIdx.x % groups;
+  if (r_dev != nullptr && r >= *r_dev) return;
+  const int cg = C / groups, vpp = cg / VE;     // vectors per pixel of this group
+  T* base = x + (long long)r * HW * c_stride + c_off + g * cg;
+  const int nv = HW * vpp, n = HW * cg;
+  __shared__ float red[kBlock];
+  float v[VPT][VE];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + k * kBlock;
+    if (i < nv) {
+      const int px = i / vpp, part = i - px * vpp;
+      float t[8];
+      if constexpr (VE == 8) load8(base + (long long)px * c_stride + part * VE, t);
+      else { const float4 f = load4(base + (long long)px * c_stride + part * VE); t[0] = f.x; t[1] = f.y; t[2] = f.z; t[3] = f.w; }
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { v[k][e] = t[e]; s += t[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[k][e] = 0.f;
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float mean = red[0] / (float)n;
+  __syncthreads();
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    if ((int)threadIdx.x + k * kBlock < nv) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { const float d = v[k][e] - mean; q += d * d; }
+    }
+  }
+  red[threadIdx.x] = q;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float rstd = 1.0f / sqrtf(red[0] / (float)n + eps);
+#pragma unroll
+  for (int k = 0; k < VPT; ++k) {
+    const int i = threadIdx.x + k * kBlock;
+    if (i < nv) {
+      const int px = i / vpp, part = i - px * vpp;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const int c = g * cg + part * VE + e;
+        float w = (v[k][e] - mean) * rstd * gamma[c] + beta[c];
+        o[e] = relu ? fmaxf(w, 0.f) : w;
+      }
+      T* dst = base + (long long)px * c_stride + part * VE;
+      if constexpr (VE == 8) store8(dst, o);
+      else store4(dst, make_float4(o[0], o[1], o[2], o[3]));
+    }
+  }
+}
+
 template <typename T>
 __global__ void gap_kernel(const T* __restrict__ in, T* __restrict__ out, int HW, int C, const int* __restrict__ r_dev) {
   // one workgroup per roi; thread t owns channels t, t+256, ... ; sequential sum over pixels (fixed order)
@@ -503,6 +578,20 @@ extern "C" int dp_groupnorm_relu_nhwc(const dp_groupnorm_params* p, dp_stream_t 
              "dp_groupnorm_relu_nhwc: bad args");
   hipStream_t s = as_stream(stream);
   const dim3 g(p->R * p->groups), b(kBlock);
+  {
+    // the register-resident form: 16-byte vectors inside one group (and 16-byte aligned rows), at most 8 (16-bit) / 16 (fp32) vectors per thread
+    const int es = p->dtype == DP_F32 ? 4 : 2, ve = 16 / es, cg = p->C / p->groups;
+    const long long nv = (long long)p->HW * (cg / ve);
+    const bool vec_ok = cg % ve == 0 && p->c_stride % ve == 0 && p->c_off % ve == 0 && (reinterpret_cast<uintptr_t>(p->x) & 15) == 0;
+    static int reg_on = -1;     // DP_GN_REG=0: A/B knob (the element-wise three-sweep kernel)
+    if (reg_on < 0) { const char* e = getenv("DP_GN_REG"); reg_on = e ? atoi(e) : 1; }
+    if (reg_on && vec_ok && nv <= (long long)kBlock * (es == 4 ? 16 : 8)) {
+      if (p->dtype == DP_F32) hipLaunchKernelGGL((groupnorm_reg_kernel<float, 16>), g, b, 0, s, (float*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu, p->r_dev);
+      else if (p->dtype == DP_BF16) hipLaunchKernelGGL((groupnorm_reg_kernel<uint16_t, 8>), g, b, 0, s, (uint16_t*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu, p->r_dev);
+      else hipLaunchKernelGGL((groupnorm_reg_kernel<f16_t, 8>), g, b, 0, s, (f16_t*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu, p->r_dev);
+      return dp_check_launch("groupnorm_reg_kernel");
+    }
+  }
   DISPATCH_DTYPE(p->dtype,
                  hipLaunchKernelGGL(groupnorm_kernel<T>, g, b, 0, s, (T*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu, p->r_dev));
   return dp_check_launch("groupnorm_kernel");
