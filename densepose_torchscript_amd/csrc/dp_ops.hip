@@ -426,11 +426,128 @@ __global__ __launch_bounds__(kBlock) void groupnorm_reg_kernel(T* __restrict__ x
   }
 }
 
+// ... and with whole 128-byte lines: one 1024-thread workgroup takes the 128 B / (cg * sizeof(T)) adjacent groups that share a cache
+// line of every pixel (4 groups of 16 bf16 channels, 8 groups of 8), eight 16-byte vectors per pixel. A thread's vectors all belong
+// to one group (1024 % 8 == 0), so the per-group statistics are a strided tree reduction over threads with equal (thread & 7).
+// One group per workgroup reads 32-byte pieces of 128-byte lines: 2 TB/s on the DeepLab head; this form moves the same bytes in full lines.
+constexpr int kGnLineThreads = 1024, kGnLineVpt = 7;
 template <typename T>
-__global__ void gap_kernel(const T* __restrict__ in, T* __restrict__ out, int HW, int C, const int* __restrict__ r_dev) {
-  // one workgroup per roi; thread t owns channels t, t+256, ... ; sequential sum over pixels (fixed order)
+__global__ __launch_bounds__(kGnLineThreads) void groupnorm_line_kernel(T* __restrict__ x, int HW, int C, int c_stride, int c_off, int groups,
+                                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                        float eps, int relu, const int* __restrict__ r_dev) {
+  constexpr int VE = 16 / sizeof(T);
+  const int cg = C / groups, vpp = cg / VE;      // vectors per pixel and group: 1, 2, 4 or 8
+  const int gw = 8 / vpp;                        // groups of this workgroup (one 128-byte line of every pixel)
+  const int wpr = groups / gw;                   // workgroups per roi
+  const int r = blockIdx.x / wpr, g0 = (blockIdx.x - r * wpr) * gw;
+  if (r_dev != nullptr && r >= *r_dev) return;
+  T* base = x + (long long)r * HW * c_stride + c_off + g0 * cg;
+  const int part = threadIdx.x & 7;              // 16-byte vector of the line: fixed per thread
+  const int gl = part / vpp;                     // group of this thread inside the workgroup
+  const int nv = HW * 8, n = HW * cg;
+  __shared__ float red[kGnLineThreads];
+  __shared__ float stat[8];
+  float v[kGnLineVpt][VE];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < kGnLineVpt; ++k) {
+    const int i = threadIdx.x + k * kGnLineThreads;
+    if (i < nv) {
+      const int px = i >> 3;
+      float t[8];
+      if constexpr (VE == 8) load8(base + (long long)px * c_stride + part * VE, t);
+      else { const float4 f = load4(base + (long long)px * c_stride + part * VE); t[0] = f.x; t[1] = f.y; t[2] = f.z; t[3] = f.w; }
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { v[k][e] = t[e]; s += t[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) v[k][e] = 0.f;
+    }
+  }
+  auto group_reduce = [&](float mine) -> float {   // sum over the threads of this thread's group (fixed order)
+    red[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = kGnLineThreads / 2; o >= 8; o >>= 1) {      // keeps (thread & 7): the 8 vector lanes stay apart
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x < 8) {
+      float t = 0.f;
+      const int first = (threadIdx.x / vpp) * vpp;
+      for (int q = 0; q < vpp; ++q) t += red[first + q];   // the vpp vector lanes of one group
+      stat[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const float out = stat[gl * vpp];
+    __syncthreads();
+    return out;
+  };
+  const float mean = group_reduce(s) / (float)n;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < kGnLineVpt; ++k) {
+    if ((int)threadIdx.x + k * kGnLineThreads < nv) {
+#pragma unroll
+      for (int e = 0; e < VE; ++e) { const float d = v[k][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(group_reduce(q) / (float)n + eps);
+  const int c0 = (g0 + gl) * cg + (part - gl * vpp) * VE;   // first channel of this thread's vectors
+  float gm[VE], bt[VE];
+#pragma unroll
+  for (int e = 0; e < VE; ++e) { gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; }
+#pragma unroll
+  for (int k = 0; k < kGnLineVpt; ++k) {
+    const int i = threadIdx.x + k * kGnLineThreads;
+    if (i < nv) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const float w = (v[k][e] - mean) * rstd * gm[e] + bt[e];
+        o[e] = relu ? fmaxf(w, 0.f) : w;
+      }
+      T* dst = base + (long long)(i >> 3) * c_stride + part * VE;
+      if constexpr (VE == 8) store8(dst, o);
+      else store4(dst, make_float4(o[0], o[1], o[2], o[3]));
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void gap_kernel(const T* __restrict__ in, T* __restrict__ out, int HW, int C, const int* __restrict__ r_dev) {
+  // one workgroup per roi. C % 8 == 0 and C / 8 divides the block: thread = (pixel lane pl, 8-channel chunk cc) reads whole 16-byte
+  // (16-bit) / 32-byte vectors, sums its pixels pl, pl + L, ... in order, and the L pixel lanes of a chunk are added in lane order
+  // through LDS - a fixed summation order, full-line reads (the first version walked 784 pixels with one 2-byte load each: 0.19 ms
+  // per step on the DeepLab head). Other channel counts: thread t owns channels t, t + 256, ..., sequential sum over the pixels.
   const int r = blockIdx.x;
   if (r_dev != nullptr && r >= *r_dev) return;
+  const int C8 = C >> 3;
+  if ((C & 7) == 0 && C8 <= kBlock && kBlock % C8 == 0) {
+    __shared__ float part[kBlock][8];
+    const int L = kBlock / C8, cc = threadIdx.x % C8, pl = threadIdx.x / C8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const T* p = in + (long long)r * HW * C + cc * 8;
+    for (int i = pl; i < HW; i += L) {
+      float t[8];
+      load8(p + (long long)i * C, t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += t[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    if (pl == 0) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s += part[l * C8 + cc][e];
+        o[e] = s / (float)HW;
+      }
+      store8(out + (long long)r * C + cc * 8, o);
+    }
+    return;
+  }
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s = 0.f;
     const T* p = in + (long long)r * HW * C + c;
@@ -583,8 +700,18 @@ extern "C" int dp_groupnorm_relu_nhwc(const dp_groupnorm_params* p, dp_stream_t 
     const int es = p->dtype == DP_F32 ? 4 : 2, ve = 16 / es, cg = p->C / p->groups;
     const long long nv = (long long)p->HW * (cg / ve);
     const bool vec_ok = cg % ve == 0 && p->c_stride % ve == 0 && p->c_off % ve == 0 && (reinterpret_cast<uintptr_t>(p->x) & 15) == 0;
-    static int reg_on = -1;     // DP_GN_REG=0: A/B knob (the element-wise three-sweep kernel)
-    if (reg_on < 0) { const char* e = getenv("DP_GN_REG"); reg_on = e ? atoi(e) : 1; }
+    static int reg_on = -1;     // DP_GN_REG=0: A/B knob (the element-wise three-sweep kernel), 1: one group per workgroup only
+    if (reg_on < 0) { const char* e = getenv("DP_GN_REG"); reg_on = e ? atoi(e) : 2; }
+    // whole-line form: the groups sharing a 128-byte line go to one workgroup
+    const int line_groups = (cg * es <= 128 && 128 % (cg * es) == 0) ? 128 / (cg * es) : 0;
+    if (reg_on >= 2 && vec_ok && line_groups >= 1 && p->groups % line_groups == 0 && (p->c_stride * es) % 128 == 0 && (p->c_off * es) % 128 == 0 &&
+        (reinterpret_cast<uintptr_t>(p->x) & 127) == 0 && (long long)p->HW * 8 <= (long long)kGnLineThreads * kGnLineVpt && p->HW * 8 >= kGnLineThreads) {
+      const dim3 gl(p->R * (p->groups / line_groups)), bl(kGnLineThreads);
+      if (p->dtype == DP_F32) hipLaunchKernelGGL(groupnorm_line_kernel<float>, gl, bl, 0, s, (float*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu, p->r_dev);
+      else if (p->dtype == DP_BF16) hipLaunchKernelGGL(groupnorm_line_kernel<uint16_t>, gl, bl, 0, s, (uint16_t*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu, p->r_dev);
+      else hipLaunchKernelGGL(groupnorm_line_kernel<f16_t>, gl, bl, 0, s, (f16_t*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu, p->r_dev);
+      return dp_check_launch("groupnorm_line_kernel");
+    }
     if (reg_on && vec_ok && nv <= (long long)kBlock * (es == 4 ? 16 : 8)) {
       if (p->dtype == DP_F32) hipLaunchKernelGGL((groupnorm_reg_kernel<float, 16>), g, b, 0, s, (float*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu, p->r_dev);
       else if (p->dtype == DP_BF16) hipLaunchKernelGGL((groupnorm_reg_kernel<uint16_t, 8>), g, b, 0, s, (uint16_t*)p->x, p->HW, p->C, p->c_stride, p->c_off, p->groups, p->gamma, p->beta, p->eps, p->relu, p->r_dev);
