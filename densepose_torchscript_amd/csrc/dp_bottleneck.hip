@@ -92,23 +92,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bottleneck_tail64_kernel(cons
   {
     const int srow = lane >> 2;
     const int scc = (lane & 3) ^ swz(srow);
-    const T* __restrict__ w2 = reinterpret_cast<const T*>(p.w2) + (long long)srow * p.kpad2 + scc * 8;
+    const unsigned char* __restrict__ w2 = reinterpret_cast<const unsigned char*>(p.w2) + dp_wtile_off(srow, 0, scc, p.kpad2 * 2 / 64);   // tiled weight matrix
     for (int piece = wave; piece < 18 * 4; piece += NW) {
       const int pl = piece >> 2, rg = piece & 3;
-      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w2 + (long long)(rg * 16) * p.kpad2 + pl * 32),
+      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w2 + ((long long)rg * (p.kpad2 * 2 / 64) + pl) * 1024),
                                        DP_LDS_PTR(w2_s + pl * 4096 + rg * 1024), 16, 0, 0);
     }
-    const T* __restrict__ w3 = reinterpret_cast<const T*>(p.w3) + (long long)srow * p.kpad3 + scc * 8;
+    const unsigned char* __restrict__ w3 = reinterpret_cast<const unsigned char*>(p.w3) + dp_wtile_off(srow, 0, scc, p.kpad3 * 2 / 64);   // tiled weight matrix
     for (int piece = wave; piece < 2 * 16; piece += NW) {
       const int pl = piece >> 4, rg = piece & 15;
-      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w3 + (long long)(rg * 16) * p.kpad3 + pl * 32),
+      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w3 + ((long long)rg * (p.kpad3 * 2 / 64) + pl) * 1024),
                                        DP_LDS_PTR(w3_s + pl * 16384 + rg * 1024), 16, 0, 0);
     }
     if (HAS_NEXT) {
-      const T* __restrict__ w1 = reinterpret_cast<const T*>(p.w1n) + (long long)srow * p.kpad1n + scc * 8;
+      const unsigned char* __restrict__ w1 = reinterpret_cast<const unsigned char*>(p.w1n) + dp_wtile_off(srow, 0, scc, p.kpad1n * 2 / 64);
       for (int piece = wave; piece < 8 * 4; piece += NW) {
         const int pl = piece >> 2, rg = piece & 3;
-        __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w1 + (long long)(rg * 16) * p.kpad1n + pl * 32),
+        __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w1 + ((long long)rg * (p.kpad1n * 2 / 64) + pl) * 1024),
                                          DP_LDS_PTR(w1_s + pl * 4096 + rg * 1024), 16, 0, 0);
       }
     }
@@ -371,23 +371,23 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
   {  // weights -> LDS, once (same images as the tile kernel)
     const int srow = lane >> 2;
     const int scc = (lane & 3) ^ swz(srow);
-    const T* __restrict__ w2 = reinterpret_cast<const T*>(p.w2) + (long long)srow * p.kpad2 + scc * 8;
+    const unsigned char* __restrict__ w2 = reinterpret_cast<const unsigned char*>(p.w2) + dp_wtile_off(srow, 0, scc, p.kpad2 * 2 / 64);   // tiled weight matrix
     for (int piece = wave; piece < 18 * 4; piece += NW) {
       const int pl = piece >> 2, rg = piece & 3;
-      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w2 + (long long)(rg * 16) * p.kpad2 + pl * 32),
+      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w2 + ((long long)rg * (p.kpad2 * 2 / 64) + pl) * 1024),
                                        DP_LDS_PTR(w2_s + pl * 4096 + rg * 1024), 16, 0, 0);
     }
-    const T* __restrict__ w3 = reinterpret_cast<const T*>(p.w3) + (long long)srow * p.kpad3 + scc * 8;
+    const unsigned char* __restrict__ w3 = reinterpret_cast<const unsigned char*>(p.w3) + dp_wtile_off(srow, 0, scc, p.kpad3 * 2 / 64);   // tiled weight matrix
     for (int piece = wave; piece < 2 * 16; piece += NW) {
       const int pl = piece >> 4, rg = piece & 15;
-      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w3 + (long long)(rg * 16) * p.kpad3 + pl * 32),
+      __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w3 + ((long long)rg * (p.kpad3 * 2 / 64) + pl) * 1024),
                                        DP_LDS_PTR(w3_s + pl * 16384 + rg * 1024), 16, 0, 0);
     }
     if (HAS_NEXT) {
-      const T* __restrict__ w1 = reinterpret_cast<const T*>(p.w1n) + (long long)srow * p.kpad1n + scc * 8;
+      const unsigned char* __restrict__ w1 = reinterpret_cast<const unsigned char*>(p.w1n) + dp_wtile_off(srow, 0, scc, p.kpad1n * 2 / 64);
       for (int piece = wave; piece < 8 * 4; piece += NW) {
         const int pl = piece >> 2, rg = piece & 3;
-        __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w1 + (long long)(rg * 16) * p.kpad1n + pl * 32),
+        __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w1 + ((long long)rg * (p.kpad1n * 2 / 64) + pl) * 1024),
                                          DP_LDS_PTR(w1_s + pl * 4096 + rg * 1024), 16, 0, 0);
       }
     }

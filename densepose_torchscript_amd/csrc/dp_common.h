@@ -125,5 +125,13 @@ __device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
 bool dp_conv_wsr_ok(const dp_conv_params* p);
 int dp_conv_wsr_launch(const dp_conv_params* p, dp_stream_t stream);
 
+// Packed weight matrices are stored in 1 KiB TILES of 16 rows x 64 bytes of K (round 3): tile (rg, plane) of a matrix with
+// n_planes = Kpad * esize / 64 K planes sits at ((rg * n_planes) + plane) * 1024, row-major inside. One LDS-DMA wave instruction (16
+// rows of one plane, what every convolution kernel stages) then reads 8 consecutive whole cache lines instead of 16 half lines from
+// rows Kpad * esize bytes apart. Byte offset of 16-byte chunk `chunk` (0..3) of row `row` in plane `plane`:
+__host__ __device__ inline long long dp_wtile_off(int row, int plane, int chunk, int n_planes) {
+  return ((long long)(row >> 4) * n_planes + plane) * 1024 + (row & 15) * 64 + chunk * 16;
+}
+
 static inline hipStream_t as_stream(dp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

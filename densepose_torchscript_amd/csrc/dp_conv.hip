@@ -140,8 +140,6 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, const f32x4 (&acc)
 template <typename T, int BN, int NPL>
 __global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int ES = sizeof(T);
-  constexpr int CH = 16 / ES;           // elements per chunk
-  constexpr int KT = NPL * 64 / ES;     // elements of K per step
   constexpr int A_PLANE = kBM * 64;
   constexpr int B_PLANE = BN * 64;
   constexpr int A_BUF = NPL * A_PLANE;
@@ -202,8 +200,10 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs 
     }
   }
   const T* __restrict__ in = reinterpret_cast<const T*>(p.in);
-  const T* __restrict__ wgt =
-      reinterpret_cast<const T*>(p.weight) + (long long)(n0 + wave * B_GROUPS * 16 + srow) * p.Kpad + scc * CH;
+  // weights: 1 KiB tiles of 16 rows x 64 B (dp_wtile_off): this lane's chunk of row group (n0 / 16 + wave * B_GROUPS), plane 0
+  const int w_planes = p.Kpad * ES / 64;
+  const unsigned char* __restrict__ wgt =
+      reinterpret_cast<const unsigned char*>(p.weight) + dp_wtile_off(n0 + wave * B_GROUPS * 16 + srow, 0, scc, w_planes);
   const T* __restrict__ zsrc = reinterpret_cast<const T*>(&g_zero16);
   unsigned char* const lds_a = smem + (wave * A_GROUPS) * 1024;           // + buf*BUF + plane*A_PLANE + i*1024
   unsigned char* const lds_b = smem + A_BUF + (wave * B_GROUPS) * 1024;   // + buf*BUF + plane*B_PLANE + i*1024
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs 
         __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(src), DP_LDS_PTR(lds_a + (BUF_IDX) * BUF + pl * A_PLANE + i * 1024), 16, 0, 0); \
       }                                                                                                           \
       _Pragma("unroll") for (int i = 0; i < B_GROUPS; ++i) {                                                      \
-        const T* wsrc = wgt + (long long)(16 * i) * p.Kpad + (KT_IDX) * KT + pl * 4 * CH;                         \
+        const unsigned char* wsrc = wgt + ((long long)i * w_planes + (KT_IDX) * NPL + pl) * 1024;                 \
         __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(wsrc), DP_LDS_PTR(lds_b + (BUF_IDX) * BUF + pl * B_PLANE + i * 1024), 16, 0, 0); \
       }                                                                                                           \
     }                                                                                                             \
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs 
 // =====================================================================================================
 constexpr int kRing = 4;
 #ifndef DP_RING_EXP
-#define DP_RING_EXP 0     // diagnostic builds: 1 = no LDS-DMA issue in the steady loop, 2 = every piece reads one contiguous (cached) KiB, 4 = weight pieces read the tile a tiled weight layout would give them
+#define DP_RING_EXP 0     // diagnostic builds: 1 = no LDS-DMA issue in the steady loop, 2 = every piece reads one contiguous (cached) KiB
 #endif
 
 template <int N>
@@ -321,7 +321,6 @@ template <typename T, int WC, int TP, bool DUAL>
 __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArgs p) {
   constexpr int ES = sizeof(T);
   constexpr int CH = 16 / ES;
-  constexpr int PE = 64 / ES;             // elements of K per plane
   constexpr int TC = 4;
   constexpr int NW = WC * 2;              // waves
   constexpr int BM = 2 * TP * 16;         // pixels
@@ -386,7 +385,9 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
       }
     }
   }
-  const int w_boff = ((n0 + wave * 32 + srow) * p.Kpad + scc * CH) * ES;
+  // weights: 1 KiB tiles of 16 rows x 64 B (dp_wtile_off): piece i of plane S = tile (n0 / 16 + wave * 2 + i, S)
+  const int w_planes = p.Kpad * ES / 64;
+  const int w_boff = (int)dp_wtile_off(n0 + wave * 32 + srow, 0, scc, w_planes);
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
   // Second source of a pointwise layer (the projection shortcut of a bottleneck's first block as extra K planes of its conv3,
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
     }                                                                                                              \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DP_LDS_PTR(lds_sb + slot_ + i * 1024), 16,                    \
-                                               w_boff + (16 * i * p.Kpad + (S_IDX) * PE) * ES, 0, 0, 0);           \
+                                               w_boff + (i * w_planes + (S_IDX)) * 1024, 0, 0, 0);                 \
     }                                                                                                              \
   }
 
@@ -530,11 +531,8 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
               else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(lds_sa + dslot + m * NW * 1024), 16, off, 0, 0, 0);
             }
           } else if constexpr (m < 4) {
-            // (DP_RING_EXP & 4: the access pattern of a weight matrix stored in 1 KiB tiles of 16 rows x 64 B - wrong data, timing only)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DP_LDS_PTR(lds_sb + dslot + (m - 2) * 1024), 16,
-                                                     (DP_RING_EXP & 2) ? lane * 16 + (m - 2) * 1024
-                                                     : (DP_RING_EXP & 4) ? (((n0 / 16 + wave * 2 + (m - 2)) * (p.Kpad * ES / 64) + (S + 3)) * 1024 + lane * 16)
-                                                     : w_boff + (16 * (m - 2) * p.Kpad + (S + 3) * PE) * ES, 0, 0, 0);
+                                                     (DP_RING_EXP & 2) ? lane * 16 + (m - 2) * 1024 : w_boff + ((m - 2) * w_planes + (S + 3)) * 1024, 0, 0, 0);
           } else if constexpr (m < 4 + TC) {
             fc_nxt[m - 4] = *reinterpret_cast<const u32x4*>(rd_b + rslot + (m - 4) * 16 * 64);
           } else {
@@ -676,7 +674,6 @@ template <typename T>
 __global__ __launch_bounds__(512, 4) void conv_ring2_kernel(const ConvArgs p) {
   constexpr int ES = sizeof(T);
   constexpr int CH = 16 / ES;
-  constexpr int PE = 64 / ES;
   constexpr int TC = 4, TP = 4;
   constexpr int BM = 256, BN = 128;
   constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64, SLOT = A_PLANE + B_PLANE;   // 24 KiB
@@ -726,7 +723,8 @@ __global__ __launch_bounds__(512, 4) void conv_ring2_kernel(const ConvArgs p) {
       }
     }
   }
-  const int w_boff = ((n0 + wave * 16 + srow) * p.Kpad + scc * CH) * ES;
+  const int w_planes = p.Kpad * ES / 64;
+  const int w_boff = (int)dp_wtile_off(n0 + wave * 16 + srow, 0, scc, w_planes);   // tile (n0 / 16 + wave, plane 0) of the tiled weight matrix
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
   unsigned char* const lds_sa = smem + wave * 2048;             // this wave's 2 KiB of an A plane
@@ -755,7 +753,7 @@ __global__ __launch_bounds__(512, 4) void conv_ring2_kernel(const ConvArgs p) {
       const int off = (a_okm[i] & tapbit) ? (a_boff[i] + tap_boff) : (int)0x80000000;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(lds_sa + slot_idx * SLOT + i * 1024), 16, off, 0, 0, 0);
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DP_LDS_PTR(lds_sb + slot_idx * SLOT), 16, w_boff + S * PE * ES, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, DP_LDS_PTR(lds_sb + slot_idx * SLOT), 16, w_boff + S * 1024, 0, 0, 0);
   };
 
   stage(0, 0, ktab_c[0]);
@@ -839,10 +837,11 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const ConvArgs p
   {
     const int srow = lane >> 2;
     const int scc = (lane & 3) ^ swz(srow);
-    const T* __restrict__ wbase = reinterpret_cast<const T*>(p.weight) + (long long)(n0 + srow) * p.Kpad + scc * 8;
+    const int w_planes = p.Kpad * 2 / 64;      // tiled weight matrix (dp_wtile_off): piece = tile (n0 / 16 + rg, kp)
+    const unsigned char* __restrict__ wbase = reinterpret_cast<const unsigned char*>(p.weight) + dp_wtile_off(n0 + srow, 0, scc, w_planes);
     for (int piece = wave; piece < KP * (NC / 16); piece += 4) {
       const int kp = piece / (NC / 16), rg = piece % (NC / 16);
-      const T* src = wbase + (long long)(rg * 16) * p.Kpad + kp * 32;
+      const unsigned char* src = wbase + ((long long)rg * w_planes + kp) * 1024;
       __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(src), DP_LDS_PTR(smem + kp * W_PLANE + rg * 1024), 16, 0, 0);
     }
     if (tid < NC) bias_s[tid] = p.bias[n0 + tid];

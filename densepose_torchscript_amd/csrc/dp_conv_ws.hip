@@ -149,9 +149,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
     const int L = cbase + fr, l64 = L & 63;
     const int rem = l64 & 31;
     const int phys = (L & ~63) + (((l64 >> 5) * 2 + ((rem >> 2) & 1)) * 16) + (rem >> 3) * 4 + (rem & 3);   // pack.py's row permutation
-    const T* __restrict__ w = reinterpret_cast<const T*>(p.w) + (long long)phys * p.kpad + h * 1152 + fq * 8;
+    // tiled weight matrix (dp_wtile_off): K step s of part h = plane h * 36 + s, this lane's chunk fq of row phys
+    const unsigned char* __restrict__ w = reinterpret_cast<const unsigned char*>(p.w) + dp_wtile_off(phys, h * 36, fq, p.kpad * 2 / 64);
 #pragma unroll
-    for (int s = 0; s < 36; ++s) wfr[s] = *reinterpret_cast<const u32x4*>(w + s * 32);
+    for (int s = 0; s < 36; ++s) wfr[s] = *reinterpret_cast<const u32x4*>(w + s * 1024);
   }
   const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + cbase + fq * 4);
 

@@ -142,11 +142,18 @@ extern "C" int dp_pack_conv_weights(const dp_pack_params* p, const float* wmat, 
       for (int t = 0; t < nt; ++t)
         for (int c = 0; c < ci; ++c) row[(size_t)k_index(g, nt, ca, t, c)] = src[t * ci + c];
     }
-    if (p->dtype == DP_F32) {
-      memcpy(static_cast<float*>(w_out) + (long long)pr * g.kpad, row.data(), sizeof(float) * (size_t)g.kpad);
-    } else {
-      uint16_t* dst = static_cast<uint16_t*>(w_out) + (long long)pr * g.kpad;
-      for (int i = 0; i < g.kpad; ++i) dst[i] = p->dtype == DP_BF16 ? f32_to_bf16(row[(size_t)i]) : f32_to_f16(row[(size_t)i]);
+    // stored in 1 KiB tiles of 16 rows x 64 bytes of K (dp_wtile_off, dp_common.h): element k of row pr = byte k * es of the row
+    const int n_planes = g.kpad * g.es / 64;
+    unsigned char* wb = static_cast<unsigned char*>(w_out);
+    for (int i = 0; i < g.kpad; ++i) {
+      const int kb = i * g.es;
+      unsigned char* dst = wb + dp_wtile_off(pr, kb / 64, (kb % 64) / 16, n_planes) + kb % 16;
+      if (p->dtype == DP_F32) {
+        memcpy(dst, &row[(size_t)i], sizeof(float));
+      } else {
+        const uint16_t h = p->dtype == DP_BF16 ? f32_to_bf16(row[(size_t)i]) : f32_to_f16(row[(size_t)i]);
+        memcpy(dst, &h, sizeof(h));
+      }
     }
   }
   // ---- tap table: one {dy, dx, c0, valid | tap << 8} per 16-byte chunk of K

@@ -61,11 +61,12 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemArgs p) {
   // ---- weights: 7 K steps (kernel rows) x 4 cout tiles of 16, straight into registers, once
   u32x4 wfr[7][4];
   {
-    const T* __restrict__ w = reinterpret_cast<const T*>(p.w) + (long long)fr * p.kpad + fq * 8;
+    // tiled weight matrix (dp_wtile_off): cout tile i, K plane dy (one kernel row = 4 cells x 8 channels = 64 bytes)
+    const unsigned char* __restrict__ w = reinterpret_cast<const unsigned char*>(p.w) + dp_wtile_off(fr, 0, fq, p.kpad * 2 / 64);
 #pragma unroll
     for (int dy = 0; dy < 7; ++dy)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wfr[dy][i] = *reinterpret_cast<const u32x4*>(w + (long long)(i * 16) * p.kpad + dy * 32);
+      for (int i = 0; i < 4; ++i) wfr[dy][i] = *reinterpret_cast<const u32x4*>(w + ((long long)i * (p.kpad * 2 / 64) + dy) * 1024);
   }
   float bias[2][8];
 #pragma unroll

@@ -19,7 +19,7 @@ def _row_perm():
 
 
 def numpy_pack(wmat, taps, bias, cin_alloc, dtype, tap_major):
-    """-> (weight [cout_w, kpad] as raw storage, ktab [n, 4], bias [cout_w], plane_major)"""
+    """-> (weight: cout_w * kpad elements of raw storage in the tiled layout, ktab [n, 4], bias [cout_w], plane_major)"""
     es = 4 if dtype == "fp32" else 2
     ch, pe = 16 // es, 64 // es
     co, nt, ci = wmat.shape
@@ -41,6 +41,8 @@ def numpy_pack(wmat, taps, bias, cin_alloc, dtype, tap_major):
         raw = t.to(torch.float16).numpy().view(np.uint16)
     else:
         raw = flat.view(np.uint32)
+    # stored in 1 KiB tiles of 16 rows x 64 bytes of K (dp_common.h dp_wtile_off): tile (row group, plane) row-major
+    raw = raw.reshape(cout_w // 16, 16, kpad // pe, pe).transpose(0, 2, 1, 3).reshape(cout_w, kpad).copy()
     ktab = np.zeros((kpad // ch, 4), dtype=np.int32)
     for kc in range(kpad // ch):
         k0 = kc * ch
