@@ -746,7 +746,8 @@ def test_batched_nms_degenerate_inputs(eng, kind):
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("multi", [True, False])
-def test_roi_align_matches_oracle(eng, dt, multi):
+@pytest.mark.parametrize("sampling", [2, 3])   # 2: the kernel with the sample geometry tabulated per ROI; 3: the per-sample kernel
+def test_roi_align_matches_oracle(eng, dt, multi, sampling):
     from densepose_torchscript_amd.engine import Act
     from oracle import ops_ref
     from oracle.ref_cpu import OracleModel
@@ -766,7 +767,7 @@ def test_roi_align_matches_oracle(eng, dt, multi):
     counts = np.array([50, 33], dtype=np.int32)
     acts = [Act(_nhwc(m, Cc, e.tdt, e.device), n_img, m.shape[2], m.shape[3], Cc) for m in maps]
     out = torch.full((n_img * max_rois, P, P, Cc), 7.0, dtype=e.tdt, device=e.device)   # garbage: the kernel owns every row
-    e.roi_align(acts, scales, torch.from_numpy(boxes).to(e.device), torch.from_numpy(counts).to(e.device), n_img, max_rois, P, 2, out)
+    e.roi_align(acts, scales, torch.from_numpy(boxes).to(e.device), torch.from_numpy(counts).to(e.device), n_img, max_rois, P, sampling, out)
     torch.cuda.synchronize()
     got = out.float().cpu().view(n_img, max_rois, P, P, Cc).permute(0, 1, 4, 2, 3)
     assert float(got[1, counts[1]:].abs().max()) == 0.0   # padded slots of the fixed-size layout are written as zeros
@@ -778,9 +779,9 @@ def test_roi_align_matches_oracle(eng, dt, multi):
             ref = torch.zeros((len(b), Cc, P, P))
             for l in range(4):
                 idx = torch.nonzero(lv == l)[:, 0]
-                ref[idx] = ops_ref.roi_align(maps[l][i:i + 1], rois[idx], P, scales[l], 2, False)
+                ref[idx] = ops_ref.roi_align(maps[l][i:i + 1], rois[idx], P, scales[l], sampling, False)
         else:
-            ref = ops_ref.roi_align(maps[0][i:i + 1], rois, P, scales[0], 2, False)
+            ref = ops_ref.roi_align(maps[0][i:i + 1], rois, P, scales[0], sampling, False)
         tol = 2e-6 if dt == "fp32" else 3e-2
         assert torch.allclose(got[i, : counts[i]], ref, atol=tol), (got[i, : counts[i]] - ref).abs().max()
 
