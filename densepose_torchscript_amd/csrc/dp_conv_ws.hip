@@ -470,6 +470,7 @@ int launch_wsr_r(WsrArgs a, hipStream_t stream) {
   a.S = a.N * a.n_strips * a.spc;
   a.n_slices = a.cout / CS;
   int groups = cus / (8 * a.n_slices);
+  if (a.over < 0) { groups += a.over; a.over = 1; }    // shared_chip = 2: -over groups of 8 * n_slices CUs are left to the other stream
   if (groups < 1) groups = 1;
   a.n_pg = groups * 8 * (a.over > 1 ? a.over : 1);     // over-decomposition: more, shorter workgroups than CUs
   a.dbg = nullptr;
@@ -541,14 +542,19 @@ int dp_conv_wsr_launch(const dp_conv_params* p, dp_stream_t stream) {
   a.Hl = p->H / 2; a.Wl = p->W / 2;
   a.post_bytes = p->post_res ? (unsigned)((long long)p->N * (p->post_mode == 2 ? (long long)a.Hl * a.Wl : (long long)p->H * p->W) * p->Cout * 2) : 0u;
   {
-    // A launch that has the chip to itself: one persistent workgroup per CU. One that runs beside another stream's launches
-    // (dp_conv_params.shared_chip): two workgroups per CU slot, each with half the steps - a static split over exactly as many
+    // A launch that has the chip to itself: one persistent workgroup per CU. One that runs beside another stream's large launches
+    // (dp_conv_params.shared_chip = 1): two workgroups per CU slot, each with half the steps - a static split over exactly as many
     // workgroups as CUs cannot rebalance when some CUs are taken, the dispatcher can with workgroups to spare; the price is a
-    // second weight prologue per CU (A/B knobs for both cases).
+    // second weight prologue per CU. One that runs beside a chain of small, latency-bound launches (shared_chip = 2: the decoder
+    // beside the proposal top-k / NMS chain): one workgroup per CU on all but one group of CUs, which stay free for that chain -
+    // its single-wave workgroups otherwise wait for a workgroup of this launch to END before they get a CU (every CU's LDS and
+    // registers are taken), which stretched the chain 2 - 3x (profiles/r3_timeline_*.txt). A/B knobs for all three cases.
     const char* es = getenv("DP_WS_OVER_SHARED");
     const char* ea = getenv("DP_WS_OVER_ALONE");
-    a.over = p->shared_chip ? (es ? atoi(es) : 2) : (ea ? atoi(ea) : 1);
-    if (a.over < 1) a.over = 1;
+    const char* er = getenv("DP_WS_RESERVE");
+    if (p->shared_chip == 2) a.over = -(er ? atoi(er) : 1);
+    else a.over = p->shared_chip ? (es ? atoi(es) : 2) : (ea ? atoi(ea) : 1);
+    if (a.over == 0) a.over = 1;
   }
   a.in_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cin * 2);
   a.out_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cout * 2);

@@ -92,7 +92,8 @@ class Engine:
         self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
         self.fuse_shortcut = _os.environ.get("DP_FUSE_SHORTCUT", "1") != "0"   # block-0 projection shortcut as K planes of conv3 (16-bit modes)
         self.decoder_fold = True      # 16-bit modes: the decoder's level sum in the conv epilogues (post_res) instead of a merge pass
-        self._shared_chip = False     # the launches being issued run beside other large launches (hint to dp_conv2d_nhwc)
+        self._shared_chip = 0         # dp_conv_params.shared_chip of the launches being issued: 1 beside other large launches, 2 beside the top-k / NMS chain
+        self.decoder_after_rpn_heads = _os.environ.get("DP_DEC_LATE", "1") != "0"   # where the decoder's side stream forks (see _phase_a)
         self._side_streams = {}
         self._graphs = {}
         self._graph_slots, self._graph_captures = set(), {}
@@ -124,7 +125,7 @@ class Engine:
         s = pool[i]
         s.wait_stream(cur)
         self._forked.setdefault(cur.cuda_stream, set()).add(i)
-        shared, self._shared_chip = self._shared_chip, True    # launches of a branch run beside the main chain (dp_conv_params.shared_chip)
+        shared, self._shared_chip = self._shared_chip, (self._shared_chip or 1)    # launches of a branch run beside the main chain (dp_conv_params.shared_chip)
         try:
             with torch.cuda.stream(s):
                 yield
@@ -220,7 +221,7 @@ class Engine:
         p.dtype = self.dt
         p.out_f32 = 1 if out_f32 else 0
         p.hi_off, p.wi_off = layer.hi_off, layer.wi_off
-        p.shared_chip = 1 if self._shared_chip else 0
+        p.shared_chip = int(self._shared_chip)
         if n_dev is not None:
             p.n_dev = n_dev.data_ptr()
         if post is not None:
@@ -306,7 +307,7 @@ class Engine:
         p.osN, p.osH, p.osW = x.H * x.W * layer.cout, x.W * layer.cout, layer.cout
         p.out = 1                      # placeholders: only NULL / non-NULL matters to the class query
         p.post_res, p.post_mode = 1, post_mode
-        p.shared_chip = 1 if self._shared_chip else 0
+        p.shared_chip = int(self._shared_chip)
         return self.lib.dp_conv2d_kernel_class(C.byref(p)) == 6
 
     def bottleneck_tail(self, l2, l3, l1n, t1, residual):
@@ -445,7 +446,7 @@ class Engine:
             self._join(outs)
         return feats
 
-    def rpn(self, feats, Hp, Wp):
+    def rpn(self, feats, Hp, Wp, after_heads=None):
         cfg = self.cfg
         Ls = self.model.layers
         n = feats["p2"].N
@@ -494,6 +495,8 @@ class Engine:
             p.cand_boxes, p.cand_scores = cand_boxes.data_ptr(), cand_scores.data_ptr()
             p.cand_level, p.cand_valid = cand_level.data_ptr(), cand_valid.data_ptr()
             p.workspace = ws.data_ptr()
+        if after_heads is not None:
+            after_heads()       # the caller's side-stream work that is to run beside the selection chain below (see _phase_a)
         # top-k + decode of all five levels in one select launch (one workgroup per image and level)
         L.check(self.lib.dp_rpn_topk_decode_levels(levels, nl, self._stream()), "dp_rpn_topk_decode_levels")
         post = cfg.rpn_post_topk
@@ -738,20 +741,32 @@ class Engine:
         if self.keep_intermediates:
             self.inter.update(feats)
         # The decoder (roi_head.py:42-79) reads only the FPN maps, not the detections: it runs on a side stream beside the
-        # RPN / box branch, whose top-k, NMS and small-M GEMM launches cannot fill the chip on their own.
+        # proposal top-k / NMS chain and the box branch. The fork point is AFTER the RPN's head convolutions: those fill the chip
+        # on their own (beside the decoder both only get slower), the chain behind them is a string of one-workgroup-per-image
+        # launches that leaves the chip empty. The decoder's persistent launches leave an eighth of the CUs to that chain
+        # (shared_chip = 2): + 2.4 % images/s, - 7 % single-frame time against forking at the FPN's end (same-box A/B).
         dec, side = None, None
+        launch_decoder = None
         if self.cfg.dp_decoder_on and self.overlap_decoder:
             cur = torch.cuda.current_stream(self.device)
             side = self._side_streams.get(cur.cuda_stream)
             if side is None:
                 side = self._side_streams[cur.cuda_stream] = torch.cuda.Stream(device=self.device)
-            side.wait_stream(cur)
-            self._shared_chip = True      # from here to the join the two streams share the chip
-            with torch.cuda.stream(side), self._stage("decoder"):
-                dec = self.decoder(feats)
+            late = self.decoder_after_rpn_heads and given_boxes is None
+
+            def launch_decoder():
+                nonlocal dec
+                side.wait_stream(cur)
+                self._shared_chip = 2 if late else 1
+                with torch.cuda.stream(side), self._stage("decoder"):
+                    dec = self.decoder(feats)
+                self._shared_chip = 1     # from here to the join the launches of this stream share the chip with the decoder's
+            if not late:
+                launch_decoder()
+                launch_decoder = None
         if given_boxes is None:
             with self._stage("rpn"):
-                props, prop_scores, prop_counts = self.rpn(feats, Hp, Wp)
+                props, prop_scores, prop_counts = self.rpn(feats, Hp, Wp, after_heads=launch_decoder)
             if self.keep_intermediates:
                 self.inter["proposals"] = (props, prop_scores, prop_counts)
             with self._stage("box_head"):
@@ -761,7 +776,7 @@ class Engine:
         if side is not None:
             cur.wait_stream(side)
             dec.t.record_stream(cur)
-            self._shared_chip = False
+            self._shared_chip = 0
         return dict(n=n, h=h, w=w, feats=feats, det_boxes=det_boxes, det_scores=det_scores, det_counts=det_counts, dec=dec)
 
     def _pinned_counts(self, key, n):
@@ -790,7 +805,7 @@ class Engine:
             pinned.copy_(st["det_counts"], non_blocking=True)
         else:
             # everything that changes the captured launch sequence is part of the key
-            key = (shape, hwc, slot, self.overlap_decoder, self.fuse_bottleneck, self.fuse_rpn_head, self.fuse_stem_pool, self.fork_levels, self.nms_reference, self.decoder_fold, self.fuse_shortcut)
+            key = (shape, hwc, slot, self.overlap_decoder, self.decoder_after_rpn_heads, self.fuse_bottleneck, self.fuse_rpn_head, self.fuse_stem_pool, self.fork_levels, self.nms_reference, self.decoder_fold, self.fuse_shortcut)
             entry = self._graphs.pop(key, None)
             if entry is None:
                 # every (stream slot / pipeline lane) of one geometry needs a graph of its own: never cap below the slots in use,

@@ -102,8 +102,10 @@ typedef struct {
    * 1 = it runs beside other large launches on other streams. The weight-stationary 3x3 kernel is a persistent launch with a
    * static split of the work over its workgroups (weights resident in registers): alone on the chip it runs one workgroup per
    * CU; with hint 1 it is split over twice as many, shorter workgroups so that the dispatcher can rebalance when some CUs are
-   * held by another stream (a one-per-CU split cannot, and loses its advantage over the tiled kernels). The result is
-   * bit-identical either way. */
+   * held by another stream (a one-per-CU split cannot, and loses its advantage over the tiled kernels);
+   * 2 = it runs beside a chain of small latency-bound launches on another stream (top-k / NMS): one workgroup per CU again, but
+   * on 7/8 of the CUs, so that the chain's workgroups find a free CU at once instead of waiting for one of this launch to end.
+   * The result is bit-identical in all three cases. */
   int32_t shared_chip;
   /* A tensor added AFTER the activation: out = act(conv + bias) + post (weight-stationary 3x3 kernel only, i.e. kernel class 6;
    * DP_ERR_UNSUPPORTED elsewhere). The DensePose decoder (roi_head.py:71-79) sums its four scale heads after their ReLUs:
