@@ -74,33 +74,51 @@ __device__ __forceinline__ void radix_pick(const unsigned int* hist, unsigned in
   }
 }
 
-__global__ void rpn_keys_kernel(const float* __restrict__ head, uint32_t* __restrict__ keys, int n_img, int cells, int A, int head_c) {
-  const long long total = (long long)n_img * cells * A;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int a = (int)(i % A);
-    const long long cell = i / A;  // img*cells + cell
-    keys[i] = f32_to_key(head[cell * head_c + a]);
-  }
-}
-
-// ---- stage 1 (large levels only): each workgroup keeps the top min(k, chunk) keys of an 8192-anchor chunk held in LDS.
-// The global top-k (ordered by key desc, anchor index asc) is a subset of the union of the per-chunk top-k's, so the
-// single-workgroup-per-image stage 2 then scans n_chunks*k candidates instead of Hi*Wi*A keys (p2: 25k instead of 202k).
-// Survivors are written in ascending anchor-index order (ordered compaction), which keeps stage 2's tie rule exact.
+// ---- stage 1, ALL levels of a batch in one launch: workgroup = (8192-anchor chunk of a level, image).
+// Small levels: the chunk's logits become sortable keys, nothing else. Large levels (>= 2 chunks): the workgroup keeps only the top
+// min(k, chunk) keys of its chunk, held in LDS. The global top-k (ordered by key desc, anchor index asc) is a subset of the union
+// of the per-chunk top-k's, so the single-workgroup-per-image stage 2 then scans n_chunks*k candidates instead of Hi*Wi*A keys
+// (p2: 25k instead of 202k). Survivors are written in ascending anchor-index order (ordered compaction), which keeps stage 2's
+// tie rule exact. (One launch per level - two chunk selections and three key conversions - was 5 launches in a row on the
+// proposal chain, ~90 us where this one takes the time of the largest.)
 constexpr int kChunk = 8192;
 constexpr int kChunkThreads = 256;
 
-__global__ __launch_bounds__(kChunkThreads) void rpn_chunk_select_kernel(const float* __restrict__ head, int cells, int A, int head_c, int n,
-                                                                        int k, int kcap, int n_chunks, uint32_t* __restrict__ cand_keys,
-                                                                        uint32_t* __restrict__ cand_idx) {
+struct RpnPrepLevel {
+  const float* head;
+  int cells, A, head_c, n, k, kcap, n_chunks, chunked;
+  uint32_t* out_keys;    // chunked: [n_img][n_chunks][kcap] candidate keys, else [n_img][n] keys
+  uint32_t* out_idx;     // chunked: the candidates' anchor indices
+};
+struct RpnPrepMulti {
+  RpnPrepLevel lv[5];
+  int first_block[6];
+  int n_levels;
+};
+
+__global__ __launch_bounds__(kChunkThreads) void rpn_prep_kernel(const RpnPrepMulti pm) {
   __shared__ uint32_t keys[kChunk];
   __shared__ unsigned int hist[256];
   __shared__ unsigned int sh_prefix, sh_need, sh_taken_gt, sh_taken_eq, sh_bucket_count;
   __shared__ unsigned int wsum_gt[kChunkThreads / 64], wsum_eq[kChunkThreads / 64], pick_tot[4];
-  const int chunk = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+  int lvl = 0;
+  while (lvl + 1 < pm.n_levels && (int)blockIdx.x >= pm.first_block[lvl + 1]) ++lvl;
+  const RpnPrepLevel& p = pm.lv[lvl];
+  const int chunk = blockIdx.x - pm.first_block[lvl], img = blockIdx.y, tid = threadIdx.x;
+  const int A = p.A, head_c = p.head_c, n = p.n, k = p.k, kcap = p.kcap, n_chunks = p.n_chunks;
   const int i0 = chunk * kChunk;
   const int len = min(kChunk, n - i0);
-  const float* hbase = head + (long long)img * cells * head_c;
+  const float* hbase = p.head + (long long)img * p.cells * head_c;
+  if (!p.chunked) {
+    uint32_t* ok = p.out_keys + (long long)img * n;
+    for (int t = tid; t < len; t += kChunkThreads) {
+      const int idx = i0 + t;
+      ok[idx] = f32_to_key(hbase[(long long)(idx / A) * head_c + (idx % A)]);
+    }
+    return;
+  }
+  uint32_t* const cand_keys = p.out_keys;
+  uint32_t* const cand_idx = p.out_idx;
   for (int t = tid; t < len; t += kChunkThreads) {
     const int idx = i0 + t;
     keys[t] = f32_to_key(hbase[(long long)(idx / A) * head_c + (idx % A)]);
@@ -331,32 +349,62 @@ inline NmsWs carve_nms_ws(void* ws, int n_img, int n_slots) {
 }
 
 constexpr int kSortThreads = 1024;
+constexpr int kSortMaxRuns = 8;
 
+// Score order of one image's candidates. The valid candidates are compacted first (block scan; the same scan counts the RUNS
+// of equal group id). The RPN's candidates arrive as one run per pyramid level, each already in (score desc, slot asc) order -
+// rpn_select_kernel wrote them so - and then the global order is a MERGE: an element's position is its position in its own run
+// plus, for every other run, the number of elements that precede it there (a binary search; the 64-bit key (score, ~slot) is
+// unique, so there are no ties to break). That is ~40 dependent LDS reads per element instead of the 91 barrier-separated passes
+// of a bitonic sort of 8192 keys (86 us -> see profiles/). Anything else (more than kSortMaxRuns runs, or a run out of order:
+// the box head's candidates) takes the bitonic sort, over the next power of two of the VALID count only.
 __global__ __launch_bounds__(kSortThreads) void nms_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                                  const int32_t* __restrict__ group, const int32_t* __restrict__ valid,
                                                                  int n_slots, int n2, int trick_max_numel, NmsWs w) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long* s = reinterpret_cast<unsigned long long*>(smem_raw);
-  __shared__ unsigned int sh_nvalid;
   __shared__ float red[kSortThreads];
+  __shared__ unsigned int wsum[kSortThreads / 64];
+  __shared__ unsigned int sh_carry;               // (runs << 16 | valid candidates) before the current slice of 1024 slots
+  __shared__ int seg_start[kSortMaxRuns + 1];     // first compacted position of run r
+  __shared__ int sh_unsorted;
   const int img = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
   const long long base = (long long)img * n_slots;
-  if (tid == 0) sh_nvalid = 0;
+  for (int i = tid; i < n2; i += kSortThreads) s[i] = 0ull;    // padding / invalid: sorts last
+  if (tid == 0) { sh_carry = 0u; sh_unsorted = 0; }
   __syncthreads();
   float mx = -INFINITY;
-  unsigned int cnt = 0;
-  for (int i = tid; i < n2; i += kSortThreads) {
-    unsigned long long e = 0ull;
-    if (i < n_slots && valid[base + i]) {
-      // +1 keeps every valid key above the 0 used for padding / invalid entries
-      e = ((unsigned long long)f32_to_key(scores[base + i]) << 32) | (uint32_t)(~(uint32_t)i);
-      ++cnt;
+  for (int i0 = 0; i0 < n_slots; i0 += kSortThreads) {
+    const int i = i0 + tid;
+    const bool in = i < n_slots;
+    const bool v = in && valid[base + i];
+    const bool bd = in && (i == 0 || group[base + i] != group[base + i - 1]);
+    const unsigned int pk = (v ? 1u : 0u) | (bd ? 0x10000u : 0u);
+    unsigned int incl = pk;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned int before = sh_carry;
+    for (int ww = 0; ww < wv; ++ww) before += wsum[ww];
+    const unsigned int excl = before + incl - pk;
+    if (bd) {
+      const unsigned int r = excl >> 16;
+      if (r < (unsigned)kSortMaxRuns) seg_start[r] = (int)(excl & 0xffffu);
+    }
+    if (v) {
+      s[excl & 0xffffu] = ((unsigned long long)f32_to_key(scores[base + i]) << 32) | (uint32_t)(~(uint32_t)i);
       const float* b = boxes + (base + i) * 4;
       mx = fmaxf(mx, fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
     }
-    s[i] = e;
+    __syncthreads();
+    if (tid == kSortThreads - 1) sh_carry = before + incl;
+    __syncthreads();
   }
-  if (cnt) atomicAdd(&sh_nvalid, cnt);
   red[tid] = mx;
   __syncthreads();
   for (int o = kSortThreads / 2; o > 0; o >>= 1) {
@@ -364,31 +412,66 @@ __global__ __launch_bounds__(kSortThreads) void nms_sort_kernel(const float* __r
     __syncthreads();
   }
   const float max_coord = red[0];
-  const int nvalid = (int)sh_nvalid;
-  bitonic_sort_desc(s, n2, tid, kSortThreads);
+  const int nvalid = (int)(sh_carry & 0xffffu);
+  const int nruns = (int)(sh_carry >> 16);
   const bool trick = (4 * nvalid <= trick_max_numel);
   const float off_unit = max_coord + 1.0f;
-  for (int i = tid; i < n_slots; i += kSortThreads) {
-    if (i < nvalid) {
-      const int slot = (int)(~(uint32_t)(s[i] & 0xffffffffull));
-      const float* b = boxes + (base + slot) * 4;
-      const int g = group[base + slot];
-      float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
-      if (trick) {
-        const float o = (float)g * off_unit;  // torchvision: boxes + idxs.to(boxes) * (boxes.max() + 1)
-        x1 = x1 + o; y1 = y1 + o; x2 = x2 + o; y2 = y2 + o;
-      }
-      float* d = w.sboxes + (base + i) * 4;
-      d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2;
-      w.sgroup[base + i] = trick ? 0 : g;  // with the trick, overlap across groups is impossible by construction
-      w.sslot[base + i] = slot;
-    } else {
-      w.sslot[base + i] = -1;
+  auto emit = [&](int i, unsigned long long e) __attribute__((always_inline)) {    // candidate e is the i-th in score order
+    const int slot = (int)(~(uint32_t)(e & 0xffffffffull));
+    const float* b = boxes + (base + slot) * 4;
+    const int g = group[base + slot];
+    float x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
+    if (trick) {
+      const float o = (float)g * off_unit;  // torchvision: boxes + idxs.to(boxes) * (boxes.max() + 1)
+      x1 = x1 + o; y1 = y1 + o; x2 = x2 + o; y2 = y2 + o;
     }
+    float* d = w.sboxes + (base + i) * 4;
+    d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2;
+    w.sgroup[base + i] = trick ? 0 : g;  // with the trick, overlap across groups is impossible by construction
+    w.sslot[base + i] = slot;
+  };
+  auto run_of = [&](int j) __attribute__((always_inline)) -> int {
+    int r = 0;
+    while (r + 1 < nruns && seg_start[r + 1] <= j) ++r;
+    return r;
+  };
+  const bool few_runs = nruns <= kSortMaxRuns;
+  if (few_runs) {
+    if (tid == 0) seg_start[nruns] = nvalid;
+    __syncthreads();
+    for (int j = tid + 1; j < nvalid; j += kSortThreads)
+      if (j > seg_start[run_of(j)] && s[j - 1] <= s[j]) sh_unsorted = 1;
+    __syncthreads();
   }
+  if (few_runs && !sh_unsorted) {
+    for (int j = tid; j < nvalid; j += kSortThreads) {
+      const unsigned long long e = s[j];
+      const int r = run_of(j);
+      int rank = j - seg_start[r];
+      for (int b = 0; b < nruns; ++b) {
+        if (b == r) continue;
+        int lo = seg_start[b], hi = seg_start[b + 1];     // first position of run b whose key is below e
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (s[mid] > e) lo = mid + 1; else hi = mid;
+        }
+        rank += lo - seg_start[b];
+      }
+      emit(rank, e);
+    }
+  } else {
+    int n2v = 2;
+    while (n2v < nvalid) n2v <<= 1;     // <= n2: the compacted keys fill [0, nvalid), zeros behind them
+    bitonic_sort_desc(s, n2v, tid, kSortThreads);
+    for (int i = tid; i < nvalid; i += kSortThreads) emit(i, s[i]);
+  }
+  for (int i = nvalid + tid; i < n_slots; i += kSortThreads) w.sslot[base + i] = -1;
   if (tid == 0) w.nvalid[img] = nvalid;
 }
 
+// 64 x 64 tiles of the suppression matrix (row i, column j > i, same group, IoU > thr), one single-wave workgroup per tile. (Tried:
+// four tiles per workgroup - the RPN's launch has 50 k workgroups, half of them below the diagonal - and deciding the pairs far from
+// the threshold without the IEEE division: 64 -> 67 and 74 us. The launch is bound by the VALU work of its 93 M pairs.)
 __global__ __launch_bounds__(64) void nms_mask_kernel(int n_slots, int ncb, float thr, NmsWs w) {
   const int cb = blockIdx.x, rb = blockIdx.y, img = blockIdx.z;
   if (cb < rb) return;
@@ -430,81 +513,87 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(int n_slots, int ncb, floa
   }
 }
 
-__global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int n_slots,
-                                                       int ncb, int max_out, NmsWs w, float* __restrict__ out_boxes,
-                                                       float* __restrict__ out_scores, int32_t* __restrict__ out_index,
-                                                       int32_t* __restrict__ out_count) {
+constexpr int kScanThreads = 256;
+
+__global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, int n_slots,
+                                                                 int ncb, int max_out, NmsWs w, float* __restrict__ out_boxes,
+                                                                 float* __restrict__ out_scores, int32_t* __restrict__ out_index,
+                                                                 int32_t* __restrict__ out_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long* remv = reinterpret_cast<unsigned long long*>(smem_raw);  // [ncb]
   unsigned long long* kmask = remv + ncb;                                       // [ncb] kept rows of a chunk
   int* kbase = reinterpret_cast<int*>(kmask + ncb);                             // [ncb] rows kept before the chunk
+  __shared__ unsigned long long sh_km;
   int n_done = 0;
-  const int img = blockIdx.x, lane = threadIdx.x;
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long base = (long long)img * n_slots;
   const int nvalid = w.nvalid[img];
-  for (int i = lane; i < ncb; i += 64) remv[i] = 0ull;
+  for (int i = tid; i < ncb; i += kScanThreads) remv[i] = 0ull;
   __syncthreads();
   int kept = 0;
   const int nchunks = (nvalid + 63) / 64;
-  // the diagonal word of the NEXT chunk is fetched before this chunk's resolve: the chunks form one dependent chain
-  // (diagonal word -> resolve -> rows of the kept boxes -> next chunk), every global round trip in it is exposed
-  unsigned long long D_next = (lane < nvalid) ? w.mask[(base + lane) * ncb] : 0ull;
+  // The chunks form one dependent chain (diagonal word -> resolve -> rows of the kept boxes -> next chunk's removal word); every
+  // global round trip in it is exposed. Wave 0 walks the chain; the diagonal word of the NEXT chunk is fetched before this chunk's
+  // resolve, and the OR of the kept rows into the later removal words is spread over all four waves so that it is ONE round trip
+  // per chunk (thread = (word, half of the chunk's rows): at most 32 independent loads each), not one per 32 kept rows per word.
+  unsigned long long D_next = (wave == 0 && lane < nvalid) ? w.mask[(base + lane) * ncb] : 0ull;
   for (int c = 0; c < nchunks && kept < max_out; ++c) {
-    const int row = c * 64 + lane;
-    const unsigned long long D = D_next;
-    if (c + 1 < nchunks) D_next = (row + 64 < nvalid) ? w.mask[(base + row + 64) * ncb + c + 1] : 0ull;
-    // Greedy resolve of the chunk on the SCALAR unit: the removal word is wave-uniform (readfirstlane tells the compiler so),
-    // and only the rows that are still alive are visited - the next kept row is the lowest set bit of `alive`, its mask word
-    // comes from v_readlane with a scalar lane index. (A 64-step loop on 64-bit VALU values cost ~3 us per chunk.)
-    const unsigned long long cur_v = remv[c];
-    unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur_v >> 32)) << 32) |
-                             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur_v & 0xffffffffull));
-    unsigned long long km = 0ull;
-    const int rows_here = min(64, nvalid - c * 64);
-    const int d_lo = (int)(unsigned)(D & 0xffffffffull), d_hi = (int)(unsigned)(D >> 32);
-    unsigned long long alive = ~cur & (rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull));
-    while (alive) {
-      const int j = __ffsll((long long)alive) - 1;
-      const unsigned long long dj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(d_hi, j) << 32) |
-                                    (unsigned long long)(unsigned)__builtin_amdgcn_readlane(d_lo, j);
-      km |= (1ull << j);
-      alive &= ~(dj | (1ull << j));     // rows below j are already clear, rows above j that j suppresses die
+    if (wave == 0) {
+      const int row = c * 64 + lane;
+      const unsigned long long D = D_next;
+      if (c + 1 < nchunks) D_next = (row + 64 < nvalid) ? w.mask[(base + row + 64) * ncb + c + 1] : 0ull;
+      // Greedy resolve of the chunk on the SCALAR unit: the removal word is wave-uniform (readfirstlane tells the compiler so),
+      // and only the rows that are still alive are visited - the next kept row is the lowest set bit of `alive`, its mask word
+      // comes from v_readlane with a scalar lane index. (A 64-step loop on 64-bit VALU values cost ~3 us per chunk.)
+      const unsigned long long cur_v = remv[c];
+      unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur_v >> 32)) << 32) |
+                               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur_v & 0xffffffffull));
+      unsigned long long km = 0ull;
+      const int rows_here = min(64, nvalid - c * 64);
+      const int d_lo = (int)(unsigned)(D & 0xffffffffull), d_hi = (int)(unsigned)(D >> 32);
+      unsigned long long alive = ~cur & (rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull));
+      while (alive) {
+        const int j = __ffsll((long long)alive) - 1;
+        const unsigned long long dj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(d_hi, j) << 32) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readlane(d_lo, j);
+        km |= (1ull << j);
+        alive &= ~(dj | (1ull << j));     // rows below j are already clear, rows above j that j suppresses die
+      }
+      // the kept rows are written out AFTER the chain (their two dependent loads - sort slot, then box - would sit in it)
+      if (lane == 0) { kmask[c] = km; kbase[c] = kept; sh_km = km; }
     }
-    // the kept rows are written out AFTER the chain (their two dependent loads - sort slot, then box - would sit in it)
-    if (lane == 0) { kmask[c] = km; kbase[c] = kept; }
+    __syncthreads();
+    const unsigned long long km = sh_km;
     n_done = c + 1;
     kept += (int)__popcll(km);
-    // OR the kept rows' masks into the removal words of later chunks (lane <-> word)
+    // OR the kept rows' masks into the removal words of the later chunks
     if (c + 1 < nchunks && kept < max_out) {
-      for (int wd = c + 1 + lane; wd < ncb; wd += 64) {
-        unsigned long long acc = remv[wd];
-        unsigned long long m = km;
-        const unsigned long long* col = w.mask + (base + (long long)c * 64) * ncb + wd;
-        while (m) {
-          // 32 independent loads per trip (the kept-row list is wave-uniform, so is this control flow): the trip count, not
-          // the bytes, sets the time of this phase - each trip waits for one L2 round trip (4 per trip: 238 us for the RPN's
-          // launch, 16 per trip: 176 us)
-          unsigned long long v[32];
+      const int n_items = (ncb - (c + 1)) * 2;
+      for (int item = tid; item < n_items; item += kScanThreads) {
+        const int wd = c + 1 + (item >> 1), half = item & 1;
+        unsigned int m = half ? (unsigned int)(km >> 32) : (unsigned int)(km & 0xffffffffull);
+        const unsigned long long* col = w.mask + (base + (long long)c * 64 + half * 32) * ncb + wd;
+        unsigned long long v[32];
 #pragma unroll
-          for (int u = 0; u < 32; ++u) {
-            v[u] = 0ull;
-            if (m) {
-              const int j = __ffsll((long long)m) - 1;
-              m &= m - 1;
-              v[u] = col[(long long)j * ncb];
-            }
+        for (int u = 0; u < 32; ++u) {
+          v[u] = 0ull;
+          if (m) {
+            const int j = __ffs((int)m) - 1;
+            m &= m - 1;
+            v[u] = col[(long long)j * ncb];
           }
-#pragma unroll
-          for (int u = 0; u < 32; ++u) acc |= v[u];
         }
-        remv[wd] = acc;
+        unsigned long long acc = 0ull;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc |= v[u];
+        if (acc) atomicOr(&remv[wd], acc);
       }
     }
     __syncthreads();
   }
-  __syncthreads();
   // emit the kept rows of every processed chunk in order: position = kept rows before the chunk + kept rows before me in it
-  for (int c = 0; c < n_done; ++c) {
+  for (int c = wave; c < n_done; c += kScanThreads / 64) {
     const int row = c * 64 + lane;
     const unsigned long long km = kmask[c];
     const int pos = kbase[c] + (int)__popcll(km & ((1ull << lane) - 1ull));
@@ -517,7 +606,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ 
       out_index[o] = slot;
     }
   }
-  if (lane == 0) out_count[img] = kept < max_out ? kept : max_out;
+  if (tid == 0) out_count[img] = kept < max_out ? kept : max_out;
 }
 
 // =====================================================================================================
@@ -818,8 +907,8 @@ extern "C" int64_t dp_rpn_topk_workspace_bytes(int n_img, int Hi, int Wi, int A)
 }
 
 namespace {
-// validates one level, launches its key extraction / chunk pre-selection, fills the select-kernel arguments
-int rpn_prepare_level(const dp_rpn_level_params* p, hipStream_t s, RpnSelArgs& a, int& n2) {
+// validates one level, fills its slot of the stage-1 launch (key extraction / chunk pre-selection) and the select-kernel arguments
+int rpn_prepare_level(const dp_rpn_level_params* p, RpnSelArgs& a, RpnPrepLevel& q, int& n2) {
   DP_REQUIRE(p->head && p->cand_boxes && p->cand_scores && p->cand_level && p->cand_valid && p->workspace, "dp_rpn_topk_decode: null pointer");
   DP_REQUIRE(p->n_img > 0 && p->Hi > 0 && p->Wi > 0 && p->A > 0 && p->A <= 3 && p->head_c >= 5 * p->A, "dp_rpn_topk_decode: bad shape");
   DP_REQUIRE(p->kmax > 0 && p->kmax <= 4096, "dp_rpn_topk_decode: kmax=%d outside (0, 4096]", p->kmax);
@@ -834,20 +923,17 @@ int rpn_prepare_level(const dp_rpn_level_params* p, hipStream_t s, RpnSelArgs& a
   a.clip_x = p->clip_x; a.clip_y = p->clip_y;
   a.cand_boxes = p->cand_boxes; a.cand_scores = p->cand_scores; a.cand_level = p->cand_level; a.cand_valid = p->cand_valid;
   uint32_t* ws = reinterpret_cast<uint32_t*>(p->workspace);
+  q.head = p->head; q.cells = p->Hi * p->Wi; q.A = p->A; q.head_c = p->head_c; q.n = (int)n; q.k = p->kmax;
   if (n >= 2 * kChunk) {
     // two-stage: per-chunk pre-selection (many workgroups), then one workgroup per image over the candidates
     const int n_chunks = (int)((n + kChunk - 1) / kChunk);
     const int kcap = p->kmax < kChunk ? p->kmax : kChunk;
-    uint32_t* ckeys = ws;
-    uint32_t* cidx = ws + (long long)p->n_img * n_chunks * kcap;
-    hipLaunchKernelGGL(rpn_chunk_select_kernel, dim3(n_chunks, p->n_img), dim3(kChunkThreads), 0, s, p->head, p->Hi * p->Wi, p->A, p->head_c,
-                       (int)n, p->kmax, kcap, n_chunks, ckeys, cidx);
-    a.keys = ckeys; a.kidx = cidx; a.n_keys = n_chunks * kcap;
+    q.chunked = 1; q.n_chunks = n_chunks; q.kcap = kcap;
+    q.out_keys = ws; q.out_idx = ws + (long long)p->n_img * n_chunks * kcap;
+    a.keys = q.out_keys; a.kidx = q.out_idx; a.n_keys = n_chunks * kcap;
   } else {
-    const long long total = n * p->n_img;
-    int g = (int)((total + 255) / 256);
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(rpn_keys_kernel, dim3(g), dim3(256), 0, s, p->head, ws, p->n_img, p->Hi * p->Wi, p->A, p->head_c);
+    q.chunked = 0; q.n_chunks = (int)((n + kChunk - 1) / kChunk); q.kcap = 0;
+    q.out_keys = ws; q.out_idx = nullptr;
     a.keys = ws; a.kidx = nullptr; a.n_keys = (int)n;
   }
   const int k = (int)(n < p->kmax ? n : p->kmax);
@@ -860,14 +946,20 @@ extern "C" int dp_rpn_topk_decode_levels(const dp_rpn_level_params* levels, int 
   DP_REQUIRE(levels && n_levels >= 1 && n_levels <= 5, "dp_rpn_topk_decode_levels: 1..5 levels");
   hipStream_t s = as_stream(stream);
   RpnSelMulti m;
-  int n2max = 1;
+  RpnPrepMulti pm;
+  int n2max = 1, n_blocks = 0;
   for (int l = 0; l < n_levels; ++l) {
     DP_REQUIRE(levels[l].n_img == levels[0].n_img, "dp_rpn_topk_decode_levels: all levels must share n_img");
     int n2 = 1;
-    const int rc = rpn_prepare_level(&levels[l], s, m.lv[l], n2);
+    const int rc = rpn_prepare_level(&levels[l], m.lv[l], pm.lv[l], n2);
     if (rc != DP_OK) return rc;
     if (n2 > n2max) n2max = n2;
+    pm.first_block[l] = n_blocks;
+    n_blocks += pm.lv[l].n_chunks;
   }
+  pm.first_block[n_levels] = n_blocks;
+  pm.n_levels = n_levels;
+  hipLaunchKernelGGL(rpn_prep_kernel, dim3(n_blocks, levels[0].n_img), dim3(kChunkThreads), 0, s, pm);
   hipLaunchKernelGGL(rpn_select_kernel, dim3(levels[0].n_img, n_levels), dim3(kSelThreads), n2max * 8, s, m);
   return dp_check_launch("rpn_select_kernel");
 }
@@ -906,7 +998,7 @@ extern "C" int dp_batched_nms(const dp_nms_params* p, dp_stream_t stream) {
   hipLaunchKernelGGL(nms_sort_kernel, dim3(p->n_img), dim3(kSortThreads), n2 * 8, s, p->boxes, p->scores, p->group, p->valid, p->n_slots, n2,
                      p->trick_max_numel, w);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(ncb, ncb, p->n_img), dim3(64), 0, s, p->n_slots, ncb, p->iou_thr, w);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(p->n_img), dim3(64), ncb * 20, s, p->boxes, p->scores, p->n_slots, ncb, p->max_out, w, p->out_boxes,
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(p->n_img), dim3(kScanThreads), ncb * 20, s, p->boxes, p->scores, p->n_slots, ncb, p->max_out, w, p->out_boxes,
                      p->out_scores, p->out_index, p->out_count);
   return dp_check_launch("nms kernels");
 }

@@ -707,6 +707,58 @@ def test_batched_nms_matches_oracle(eng, n_slots, groups, reference, monkeypatch
         assert np.array_equal(os_[i, :cnt].cpu().numpy(), scores[i][keep])
 
 
+@pytest.mark.parametrize("reference", ["cuda", "cpu"])
+@pytest.mark.parametrize("layout", ["rpn", "rpn_one_run_unsorted", "nine_runs"])
+def test_batched_nms_presorted_runs(eng, layout, reference, monkeypatch):
+    """The RPN's candidate layout: one run of slots per pyramid level, each run already in score order (ties between and inside
+    runs, invalid candidates anywhere, an all-padding tail) - nms_sort_kernel merges the runs instead of sorting. One run out of
+    order, or more runs than the merge handles, must fall back to the sort and give the same answer. Tied scores only with the
+    coordinate-offset strategy ("cuda": 4 * 4119 <= 20000), whose order is score, then index; torchvision's per-group strategy
+    ("cpu" at this size) orders the survivors with an unstable sort, so that case gets distinct scores."""
+    from oracle import ops_ref
+    from densepose_torchscript_amd.engine import NMS_TRICK_MAX_NUMEL
+    e = eng["fp32"]
+    monkeypatch.setattr(e, "nms_reference", reference)
+    rng = np.random.default_rng(5)
+    n_img = 2
+    run_len = [1000, 1000, 1000, 700, 300, 119] if layout != "nine_runs" else [500] * 9
+    n_slots = sum(run_len)
+    boxes = np.stack([_random_boxes(rng, n_slots) for _ in range(n_img)])
+    scores = np.zeros((n_img, n_slots), np.float32)
+    group = np.zeros((n_img, n_slots), np.int32)
+    valid = np.ones((n_img, n_slots), np.int32)
+    for i in range(n_img):
+        o = 0
+        distinct = rng.permutation(n_slots).astype(np.float32) / 64 - 30
+        for g, ln in enumerate(run_len):
+            sc = np.sort(rng.integers(-40, 40, ln).astype(np.float32) / 8)[::-1]     # few distinct values: many ties
+            if reference == "cpu":
+                sc = np.sort(distinct[o:o + ln])[::-1]
+            scores[i, o:o + ln], group[i, o:o + ln] = sc, g
+            valid[i, o:o + ln] = rng.random(ln) > 0.05
+            if g == 3:                      # a level with fewer anchors than slots: padding (score 0, invalid) behind the real ones
+                scores[i, o + ln - 80:o + ln], valid[i, o + ln - 80:o + ln] = (0.0 if reference == "cuda" else -1000.0 - i), 0
+            if g == 4 and i == 1:
+                valid[i, o:o + ln] = 0      # a run without a single valid candidate
+            o += ln
+        if layout == "rpn_one_run_unsorted":
+            scores[i, 1200], scores[i, 1700] = scores[i, 1700], scores[i, 1200] + 1.0
+    dev = e.device
+    ob, os_, oi, oc = e.nms(torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), torch.from_numpy(group).to(dev),
+                            torch.from_numpy(valid).to(dev), n_img, n_slots, 0.7, 1000)
+    torch.cuda.synchronize()
+    for i in range(n_img):
+        v = valid[i].astype(bool)
+        idx = np.nonzero(v)[0]
+        keep = ops_ref.batched_nms(torch.from_numpy(boxes[i][v]), torch.from_numpy(scores[i][v]), torch.from_numpy(group[i][v]).long(), 0.7,
+                                   trick_max_numel=NMS_TRICK_MAX_NUMEL[e.nms_reference])
+        keep = idx[keep.numpy()][:1000]
+        cnt = int(oc[i])
+        assert cnt == len(keep)
+        assert np.array_equal(oi[i, :cnt].cpu().numpy(), keep)
+        assert np.array_equal(os_[i, :cnt].cpu().numpy(), scores[i][keep])
+
+
 @pytest.mark.parametrize("kind", ["all_invalid", "clusters", "identical"])
 def test_batched_nms_degenerate_inputs(eng, kind):
     """No valid candidate (count 0), dense clusters where most boxes are suppressed by an earlier one of their cluster, and
