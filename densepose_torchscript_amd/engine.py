@@ -95,6 +95,8 @@ class Engine:
         self._shared_chip = 0         # dp_conv_params.shared_chip of the launches being issued: 1 beside other large launches, 2 beside the top-k / NMS chain
         self.decoder_after_rpn_heads = _os.environ.get("DP_DEC_LATE", "1") != "0"   # where the decoder's side stream forks (see _phase_a)
         self._side_streams = {}
+        self._stream_handles = set()   # HIP streams in use by this engine and its predictor (new_stream)
+        self._capture_stream = None
         self._graphs = {}
         self._graph_slots, self._graph_captures = set(), {}
         self._meta_cache = {}
@@ -107,6 +109,20 @@ class Engine:
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def new_stream(self):
+        """A HIP stream that is none of the streams this engine already uses and not the current one. torch.cuda.Stream() hands
+        out 32 pooled streams round-robin, whoever asks: after enough predictors have lived in a process two logical streams of
+        one engine - a fork stream and the stream being captured, say - can be the SAME HIP stream, the fork / join events then
+        wait on their own stream, and hipGraphLaunch of the graph captured that way crashed inside the runtime
+        (hip::Graph::UpdateStreams; tools/ history: seventh predictor of a pytest process)."""
+        taken = self._stream_handles | {torch.cuda.current_stream(self.device).cuda_stream}
+        for _ in range(64):
+            s = torch.cuda.Stream(device=self.device)
+            if s.cuda_stream not in taken:
+                break
+        self._stream_handles.add(s.cuda_stream)
+        return s
 
     @contextlib.contextmanager
     def _branch(self, i, group=1):
@@ -121,7 +137,7 @@ class Engine:
         cur = torch.cuda.current_stream(self.device)
         pool = self._side_streams.setdefault(("fork", cur.cuda_stream), [])
         while len(pool) <= i:
-            pool.append(torch.cuda.Stream(device=self.device))
+            pool.append(self.new_stream())
         s = pool[i]
         s.wait_stream(cur)
         self._forked.setdefault(cur.cuda_stream, set()).add(i)
@@ -755,7 +771,7 @@ class Engine:
             cur = torch.cuda.current_stream(self.device)
             side = self._side_streams.get(cur.cuda_stream)
             if side is None:
-                side = self._side_streams[cur.cuda_stream] = torch.cuda.Stream(device=self.device)
+                side = self._side_streams[cur.cuda_stream] = self.new_stream()
             late = self.decoder_after_rpn_heads and given_boxes is None
 
             def launch_decoder():
@@ -831,7 +847,9 @@ class Engine:
                 pinned = self._pinned_counts(key, n)
                 graph = torch.cuda.CUDAGraph()
                 flops0 = self.flops_last
-                with torch.cuda.graph(graph):
+                if self._capture_stream is None:
+                    self._capture_stream = self.new_stream()    # not torch's process-wide default capture stream: see new_stream
+                with torch.cuda.graph(graph, stream=self._capture_stream):
                     st = self._phase_a(static_in, None, hwc)
                     pinned.copy_(st["det_counts"], non_blocking=True)
                 entry = (graph, static_in, st, pinned, self.flops_last - flops0, key)
@@ -931,7 +949,7 @@ class Engine:
         if isinstance(images_u8, (list, tuple)):
             images_u8 = torch.stack(images_u8)
         if not hasattr(self, "_streams") or len(self._streams) < g:
-            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(g)]
+            self._streams = [self.new_stream() for _ in range(g)]
         main = torch.cuda.current_stream(self.device)
         bounds = [(i * n) // g for i in range(g + 1)]
         states = []

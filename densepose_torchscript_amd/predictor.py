@@ -29,9 +29,9 @@ class _HostFrameRing:
     `slots` buffers per frame geometry rotate; a slot is rewritten only after its previous upload has completed (host wait on
     its event, normally long past) and its device landing buffer only after the resize kernel that read it has run."""
 
-    def __init__(self, device, slots=3, workers=4):
+    def __init__(self, device, copy_stream, slots=3, workers=4):
         self.device, self.n_slots = device, slots
-        self.copy_stream = torch.cuda.Stream(device=device)
+        self.copy_stream = copy_stream
         self.rings = {}      # (n, frame shape) -> [slot dicts]
         self.cursor = {}
         # the gather into the pinned slot is plain memcpy work: a few worker threads (ctypes.memmove releases the GIL) instead of
@@ -142,7 +142,7 @@ class DensePosePredictor:
             if all(not v.is_cuda for v in views):
                 # host-resident frames (the reference's boundary): pinned ring + one H2D per batch on the copy stream
                 if self._host_ring is None:
-                    self._host_ring = _HostFrameRing(self.device)
+                    self._host_ring = _HostFrameRing(self.device, self.engine.new_stream())
                 dev, slot = self._host_ring.upload(views, cur)
                 if identity:
                     out = dev.clone()      # (the engine keeps reading its batch after this slot has been handed out again)
@@ -157,7 +157,7 @@ class DensePosePredictor:
         # "host": torch's CPU uint8 kernel exactly as the reference runs it; the resized frames go up through the same ring
         small = [F.interpolate(c.cpu()[None], scale_factor=k, mode="bilinear", align_corners=False)[0] for c in chws]
         if self._host_ring is None:
-            self._host_ring = _HostFrameRing(self.device)
+            self._host_ring = _HostFrameRing(self.device, self.engine.new_stream())
         dev, slot = self._host_ring.upload(small, cur)
         out = dev.clone()                    # the batch tensor outlives the slot (graph replay copies from it later)
         slot["consumed"].record(cur)
@@ -188,7 +188,7 @@ class DensePosePredictor:
             lane, stream = 0, cur
             if self.pipeline_depth > 1:
                 if len(self._lanes) < self.pipeline_depth:
-                    self._lanes = [torch.cuda.Stream(device=self.device) for _ in range(self.pipeline_depth)]
+                    self._lanes = [self.engine.new_stream() for _ in range(self.pipeline_depth)]
                 lane = self._next_lane
                 self._next_lane = (lane + 1) % self.pipeline_depth
                 stream = self._lanes[lane]

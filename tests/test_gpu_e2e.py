@@ -543,6 +543,35 @@ def test_fused_launches_equal_layer_by_layer_end_to_end(dtype, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_stream_schedule_does_not_change_the_results(dtype):
+    """Where the decoder's side stream forks (after the RPN heads, at the FPN's end, or not at all), with graphs and pipeline
+    lanes or launch by launch on one stream: the same kernels on the same data, so the same bits."""
+    from densepose_torchscript_amd import get_config, make_synthetic_state
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    cfg = get_config("densepose_rcnn_R_50_FPN_s1x", ["INPUT.MIN_SIZE_TEST", 256, "INPUT.MAX_SIZE_TEST", 400, "TEST.DETECTIONS_PER_IMAGE", 5])
+    state = make_synthetic_state(cfg, 4)
+    rng = np.random.default_rng(29)
+    batches = [[torch.from_numpy(rng.integers(0, 256, (256, 400, 3), dtype=np.uint8)).cuda() for _ in range(3)] for _ in range(3)]
+
+    def run(after_heads, overlap, graphs):
+        pred = DensePosePredictor(cfg, state, dtype=dtype, resize="device", use_graphs=graphs, pipeline_depth=2 if graphs else 1)
+        pred.engine.decoder_after_rpn_heads, pred.engine.overlap_decoder = after_heads, overlap
+        outs = [pred.predict_batch(b) for b in batches] + [pred.predict_batch(batches[0])]    # the 4th replays lane 0's graph
+        pred.join()
+        torch.cuda.synchronize()
+        return [[{k: v.cpu() for k, v in r.items()} for r in o] for o in outs]
+
+    want = run(False, False, False)
+    assert sum(int(r["scores"].shape[0]) for o in want for r in o) > 0
+    for after_heads, overlap, graphs in ((True, True, True), (False, True, True), (True, True, False)):
+        got = run(after_heads, overlap, graphs)
+        for wo, go in zip(want, got):
+            for w, g in zip(wo, go):
+                for k in w:
+                    assert torch.equal(w[k], g[k]), (after_heads, overlap, graphs, k)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_frames_of_the_test_size_skip_the_resize(dtype):
     """A frame whose shortest edge already is MIN_SIZE_TEST has scale 1 (defaults.py:84-89): the uint8 resize is the identity and
     the engine reads the frames as handed over (interleaved HWC, dp_preprocess_params.src_hwc) - device frames, host frames,
