@@ -59,6 +59,8 @@ struct ConvArgs {
   const void* head_w;     // fused 1x1 head (RPN): plain [16][Cout] storage type, rows = head channels
   const float* head_b;    // [16]
   float* head_out;        // [M][16] fp32
+  int split_k;            // > 1: the K planes are cut into split_k segments, workgroup (tile, blockIdx.y) accumulates segment blockIdx.y
+  float* split_ws;        //      and writes its raw fp32 sums to split_ws[segment][M][Cout] (dp_conv_params.split_k)
 };
 
 // 16 zero bytes in global memory: out-of-image / K-padding chunks are loaded from here, so every staging load is
@@ -131,6 +133,54 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, const f32x4 (&acc)
         else store8(reinterpret_cast<T*>(p.out) + ob + c, v);
       }
     }
+  }
+}
+
+// split-K epilogue: the raw fp32 accumulators of one K segment -> ws[M][Cout] of that segment (no bias, no activation; the
+// accumulator layout is store_tile's: two runs of 8 consecutive couts per lane and pixel)
+template <int TP>
+__device__ __forceinline__ void store_tile_partial(float* __restrict__ ws, int M, int Cout, const f32x4 (&acc)[4][TP], int m_wave, int n_wave,
+                                                   int fr, int fq) {
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    const int m = m_wave + j * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = n_wave + h * 32 + fq * 8;
+      if (c >= Cout) continue;
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] = acc[2 * h][j][k]; v[4 + k] = acc[2 * h + 1][j][k]; }
+      store8(ws + (long long)m * Cout + c, v);
+    }
+  }
+}
+
+// out[m][c] = act(bias[c] + ws[0][m][c] + ws[1][m][c] + ...), segments added in index order: the summation order of a pixel is
+// fixed by the LAYER (its segment count), not by the batch or the tile it lands in
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, long long M, int Cout, const float* __restrict__ bias,
+                                                             int relu, T* __restrict__ out, long long osW) {
+  const int C8 = Cout >> 3;
+  const long long total = M * C8, seg = M * Cout;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long m = i / C8;
+    const int c = (int)(i - m * C8) * 8;
+    float v[8], t[8];
+    load8(ws + m * Cout + c, v);
+    for (int sg = 1; sg < S; ++sg) {
+      load8(ws + sg * seg + m * Cout + c, t);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += t[k];
+    }
+    load8(bias + c, t);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[k] += t[k];
+      if (relu) v[k] = fmaxf(v[k], 0.f);
+    }
+    store8(out + m * osW + c, v);
   }
 }
 
@@ -317,7 +367,9 @@ __device__ __forceinline__ void wait_planes(int planes, int pw) {
 // DUAL: the pointwise layer has a second source (dp_conv_params.in2). A template parameter, not a runtime flag: the extra per-lane
 // offsets, the second buffer resource and the per-plane source select cost the 224- and 256-row instances 21 - 25 % when they are
 // merely PRESENT in the kernel (scalar registers 97 - 100 of 102), measured in round 3.
-template <typename T, int WC, int TP, bool DUAL>
+// SPLIT: split-K launch (dp_conv_params.split_k): grid.y = segment, K planes [seg * per, ...), raw fp32 sums to the workspace.
+// A template parameter for the reason DUAL is one.
+template <typename T, int WC, int TP, bool DUAL, bool SPLIT = false>
 __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArgs p) {
   constexpr int ES = sizeof(T);
   constexpr int CH = 16 / ES;
@@ -385,9 +437,18 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
       }
     }
   }
+  // split-K: this workgroup's K segment = planes [s_base, s_base + ns) (tap validity above is per TAP, from the table's head)
+  int ns = p.n_ktiles * 2;  // number of 64-byte planes along K
+  int s_base = 0;
+  if constexpr (SPLIT) {
+    const int per = (ns + p.split_k - 1) / p.split_k;
+    s_base = blockIdx.y * per;
+    ns = min(per, ns - s_base);
+  }
+  const __attribute__((address_space(4))) i32x4* ktab_k = ktab_c + s_base * 4;
   // weights: 1 KiB tiles of 16 rows x 64 B (dp_wtile_off): piece i of plane S = tile (n0 / 16 + wave * 2 + i, S)
   const int w_planes = p.Kpad * ES / 64;
-  const int w_boff = (int)dp_wtile_off(n0 + wave * 32 + srow, 0, scc, w_planes);
+  const int w_boff = (int)dp_wtile_off(n0 + wave * 32 + srow, 0, scc, w_planes) + s_base * 1024;
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
   // Second source of a pointwise layer (the projection shortcut of a bottleneck's first block as extra K planes of its conv3,
@@ -459,7 +520,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
       __builtin_amdgcn_s_barrier();                                                                                \
       if ((S_IDX) + 3 < ns) {                                                                                      \
         DP_RING_STAGE((S_IDX) + 3, e_nx);                                                                          \
-        e_nx = ktab_c[((S_IDX) + 4 < ns ? (S_IDX) + 4 : (S_IDX) + 3) * 4];                                         \
+        e_nx = ktab_k[((S_IDX) + 4 < ns ? (S_IDX) + 4 : (S_IDX) + 3) * 4];                                         \
       }                                                                                                            \
       DP_RING_READ((S_IDX) + 1, FP_NXT, FC_NXT);                                                                   \
     }                                                                                                              \
@@ -469,15 +530,14 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
     __builtin_amdgcn_s_setprio(0);                                                                                 \
   }
 
-  const int ns = p.n_ktiles * 2;  // number of 64-byte planes along K
   {
-    const i32x4 t0 = ktab_c[0];
+    const i32x4 t0 = ktab_k[0];
     DP_RING_STAGE(0, t0);
-    if (ns > 1) { const i32x4 t1 = ktab_c[4]; DP_RING_STAGE(1, t1); }
-    if (ns > 2) { const i32x4 t2 = ktab_c[8]; DP_RING_STAGE(2, t2); }
+    if (ns > 1) { const i32x4 t1 = ktab_k[4]; DP_RING_STAGE(1, t1); }
+    if (ns > 2) { const i32x4 t2 = ktab_k[8]; DP_RING_STAGE(2, t2); }
   }
   // tap entry (wave-uniform, scalar load) of the plane staged in the NEXT step: fetched one step ahead of its use
-  i32x4 e_nx = ktab_c[(ns > 3 ? 3 : 0) * 4];
+  i32x4 e_nx = ktab_k[(ns > 3 ? 3 : 0) * 4];
 
   u32x4 fpA[TP], fcA[TC], fpB[TP], fcB[TC];
   // plane 0 landed once at most planes 1 and 2 (4 LDS-DMAs per plane per wave) are outstanding
@@ -509,7 +569,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
         // sits out a scalar-cache round trip after every barrier (round 3: the same source compiled to a 128x256 instance 23 %
         // slower after an unrelated template parameter was added; the ISA differed in exactly this placement).
         __builtin_amdgcn_sched_barrier(0);
-        e_nx = ktab_c[min(S + 4, ns - 1) * 4];
+        e_nx = ktab_k[min(S + 4, ns - 1) * 4];
         __builtin_amdgcn_sched_barrier(0);
       }
       // memory instructions spread evenly over the MFMA groups
@@ -617,7 +677,8 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
   }
 
   // ---- epilogue straight from the accumulators ----
-  store_tile<T, TP>(p, acc, m0 + wp * TP * 16, n0 + wc * 64, fr, fq);
+  if constexpr (SPLIT) store_tile_partial<TP>(p.split_ws + (long long)blockIdx.y * p.M * p.Cout, p.M, p.Cout, acc, m0 + wp * TP * 16, n0 + wc * 64, fr, fq);
+  else store_tile<T, TP>(p, acc, m0 + wp * TP * 16, n0 + wc * 64, fr, fq);
 }
 #undef DP_RING_STAGE
 #undef DP_RING_READ
@@ -638,6 +699,28 @@ int launch_conv_ring_d(const ConvArgs& a, hipStream_t stream) {
 template <typename T, int WC, int TP>
 int launch_conv_ring(const ConvArgs& a, hipStream_t stream) {
   return a.in2 ? launch_conv_ring_d<T, WC, TP, true>(a, stream) : launch_conv_ring_d<T, WC, TP, false>(a, stream);
+}
+// split-K: grid (tiles, segments) of the SPLIT instance, then the reduction + bias + activation pass (16-bit storage only)
+template <typename T, int WC, int TP>
+int launch_conv_ring_split(const ConvArgs& a, int n_seg, hipStream_t stream) {
+  if constexpr (sizeof(T) != 2) {
+    return dp_fail(DP_ERR_UNSUPPORTED, "dp_conv2d_nhwc: split_k needs 16-bit storage");
+  } else {
+    constexpr int BM = 2 * TP * 16, BN = WC * 64;
+    constexpr int lds = kRing * (BM + BN) * 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<T, WC, TP, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_ring_kernel<T, WC, TP, false, true>), dim3(a.n_tiles, n_seg), dim3(WC * 2 * 64), lds, stream, a);
+    const long long items = (long long)a.M * (a.Cout / 8);
+    int g = (int)((items + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(g), dim3(256), 0, stream, a.split_ws, n_seg, (long long)a.M, a.Cout, a.bias, a.relu,
+                       reinterpret_cast<T*>(a.out), a.osW);
+    return dp_check_launch("conv_ring_kernel (split-K)");
+  }
 }
 
 template <typename T, int BN, int NPL>
@@ -1114,14 +1197,25 @@ static int choose_ring256_tp(const dp_conv_params* p, long long M) {
   return best;
 }
 
+static bool split_uses_256(const dp_conv_params* p, long long M) {
+  const int es = p->dtype == DP_F32 ? 4 : 2;
+  const int planes = p->Kpad * es / 64;
+  const int per = (planes + p->split_k - 1) / p->split_k;
+  const int n_seg = (planes + per - 1) / per;
+  return p->Cout % 256 == 0 && p->Cout_w % 256 == 0 && ((M + 255) / 256) * (p->Cout / 256) * n_seg >= (3 * num_cus()) / 5;
+}
+
 extern "C" int dp_conv2d_kernel_class(const dp_conv_params* p) {
   if (!p) return -1;
-  return choose_conv_kernel(p, (long long)p->N * p->Ho * p->Wo);
+  const long long M = (long long)p->N * p->Ho * p->Wo;
+  if (p->split_k > 1) return split_uses_256(p, M) ? DP_CONV_RING256 : DP_CONV_RING128;
+  return choose_conv_kernel(p, M);
 }
 
 extern "C" int dp_conv2d_tile_rows(const dp_conv_params* p) {
   if (!p) return -1;
   const long long M = (long long)p->N * p->Ho * p->Wo;
+  if (p->split_k > 1) return split_uses_256(p, M) ? 256 : 128;
   switch (choose_conv_kernel(p, M)) {
     case DP_CONV_RING256: return 32 * choose_ring256_tp(p, M);
     case DP_CONV_RING256x128: return 256;
@@ -1168,6 +1262,7 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   a.n_dev = p->n_dev;
   a.in2 = p->in2; a.H2 = p->H2; a.W2 = p->W2; a.Cin2 = p->Cin2; a.stride2 = p->stride2;
   a.in2_bytes = p->in2 ? (unsigned)((long long)p->N * p->H2 * p->W2 * p->Cin2 * es) : 0u;
+  a.split_k = 0; a.split_ws = nullptr;
   if (p->in2) {
     DP_REQUIRE(p->ntaps == 1 && p->stride == 1 && p->hi_off == 0 && p->wi_off == 0 && p->H == p->Ho && p->W == p->Wo,
                "dp_conv2d_nhwc: a second source needs a pointwise stride-1 layer");
@@ -1180,6 +1275,33 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   a.out_linear = (p->osH == (long long)p->Wo * p->osW && p->osN == (long long)p->Ho * p->osH) ? 1 : 0;
   a.res_linear = (p->residual && p->rshift == 0 && p->rsH == (long long)p->Wo * p->rsW && p->rsN == (long long)p->Ho * p->rsH) ? 1 : 0;
   hipStream_t s = as_stream(stream);
+  if (p->split_k > 1) {
+    // Split-K (long-K layers with few pixel tiles: the box head's fc1, res5's 3x3): the K planes are cut into split_k segments,
+    // each (tile, segment) workgroup writes fp32 partial sums, one pass adds them in segment order (+ bias, activation). The
+    // segment count belongs to the LAYER - the caller passes the same value whatever the batch - so a pixel's summation order is
+    // fixed; what depends on the launch is only the tile shape: 256 x 256 once that gives about a chip of workgroups, else 128 x 128.
+    const bool ring_ok = (p->Cin * es) % 64 == 0 && p->ntaps >= 1 && p->ntaps <= 32 &&
+                         (long long)p->N * p->H * p->W * p->Cin * es < (1ll << 31) && (long long)p->Cout_w * p->Kpad * es < (1ll << 31);
+    if (!(es == 2 && ring_ok && p->split_ws && !p->residual && !p->head_out && !p->in2 && !p->post_res && !p->out_f32 && !p->n_dev && a.out_linear &&
+          p->out && p->Cout % 128 == 0))
+      return dp_fail(DP_ERR_UNSUPPORTED, "dp_conv2d_nhwc: split_k needs a 16-bit layer the LDS-ring kernels take, a plain NHWC output, a workspace, and "
+                                          "no residual / head / second source / post_res / n_dev");
+    const int planes = p->Kpad * es / 64;
+    const int per = (planes + p->split_k - 1) / p->split_k;
+    const int n_seg = (planes + per - 1) / per;      // every segment non-empty
+    a.split_k = p->split_k; a.split_ws = reinterpret_cast<float*>(p->split_ws);
+    const long long t256 = ((M + 255) / 256) * (p->Cout / 256);
+    if (split_uses_256(p, M)) {
+      a.tiles_n = p->Cout / 256;
+      a.n_tiles = (int)t256;
+      if (p->dtype == DP_BF16) return launch_conv_ring_split<uint16_t, 4, 8>(a, n_seg, s);
+      return launch_conv_ring_split<f16_t, 4, 8>(a, n_seg, s);
+    }
+    a.tiles_n = (p->Cout + 127) / 128;
+    a.n_tiles = (int)((M + 127) / 128) * a.tiles_n;
+    if (p->dtype == DP_BF16) return launch_conv_ring_split<uint16_t, 2, 4>(a, n_seg, s);
+    return launch_conv_ring_split<f16_t, 2, 4>(a, n_seg, s);
+  }
   const int kc = choose_conv_kernel(p, M);
   if (kc < 0) return dp_fail(DP_ERR_UNSUPPORTED, "dp_conv2d_nhwc: a second source needs a shape the LDS-ring kernels take");
   if (p->head_out) {

@@ -91,6 +91,7 @@ class Engine:
         self.fuse_bottleneck = True   # res2 blocks: conv2 -> conv3 -> next conv1 in one launch (bottleneck_tail)
         self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
         self.fuse_shortcut = _os.environ.get("DP_FUSE_SHORTCUT", "1") != "0"   # block-0 projection shortcut as K planes of conv3 (16-bit modes)
+        self.split_k_on = _os.environ.get("DP_SPLIT_K", "1") != "0"   # A/B knob: layers with PackedConv.split_k run unsplit
         self.decoder_fold = True      # 16-bit modes: the decoder's level sum in the conv epilogues (post_res) instead of a merge pass
         self._shared_chip = 0         # dp_conv_params.shared_chip of the launches being issued: 1 beside other large launches, 2 beside the top-k / NMS chain
         self.decoder_after_rpn_heads = _os.environ.get("DP_DEC_LATE", "1") != "0"   # where the decoder's side stream forks (see _phase_a)
@@ -243,6 +244,13 @@ class Engine:
         if post is not None:
             assert post.C == layer.cout and post.N == N and (post.H, post.W) == ((Ho, Wo) if post_mode == 1 else (Ho // 2, Wo // 2))
             p.post_res, p.post_mode = post.t.data_ptr(), post_mode
+        split_ws = None
+        if (getattr(layer, "split_k", 0) > 1 and self.split_k_on and residual is None and head is None and in2 is None and post is None
+                and n_dev is None and not out_f32 and out_geom is None and out_c_stride is None and N * Ho * Wo > 0):
+            # long-K layers (fc1, res5's 3x3): K in layer.split_k segments of fp32 partial sums + one reduction pass - the count is
+            # the layer's, whatever the batch (dp_conv_params.split_k)
+            split_ws = self._empty((layer.split_k, N * Ho * Wo, layer.cout), torch.float32)
+            p.split_k, p.split_ws = layer.split_k, split_ws.data_ptr()
         flops = 2 * (layer.macs_per_pixel + (head[2] if head is not None else 0)) * N * Ho * Wo
         if self.prof is not None and N * Ho * Wo > 0:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -254,6 +262,8 @@ class Engine:
                 cls = "conv_ring_kernel<%dx%s" % (self.lib.dp_conv2d_tile_rows(C.byref(p)), cls.split("x")[1])
                 if in2 is not None:                   # ... and per source count (the two-source form is its own instance)
                     cls = cls[:-1] + ",2src>"
+                if split_ws is not None:              # ... and the split-K form (+ its reduction pass)
+                    cls = cls[:-1] + ",splitk%d>" % layer.split_k
             if cls == "conv3x3_wsr_kernel":           # ... and per (channels, ReLU) for the weight-stationary kernel
                 cls = "conv3x3_wsr_kernel<%d,%s%s>" % (x.C, "relu" if relu else "linear", ",post%d" % post_mode if post is not None else "")
             es = x.t.element_size()

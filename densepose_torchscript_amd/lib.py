@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("DP_HIP_LIB") or os.path.join(_HERE, "libdensepose_hip
 CSRC = os.path.join(_HERE, "csrc")
 
 DP_F32, DP_BF16, DP_F16 = 0, 1, 2
-ABI_VERSION = 3   # == DP_ABI_VERSION of include/densepose_hip.h (bumped whenever a params struct or the symbol set changes)
+ABI_VERSION = 4   # == DP_ABI_VERSION of include/densepose_hip.h (bumped whenever a params struct or the symbol set changes)
 
 # user-facing dtype names -> (enum, element size)
 DTYPES = {"fp32": DP_F32, "float32": DP_F32, "bf16": DP_BF16, "bfloat16": DP_BF16, "fp16": DP_F16, "float16": DP_F16, "half": DP_F16}
@@ -38,7 +38,8 @@ class ConvParams(C.Structure):
                 ("hi_off", c_i32), ("wi_off", c_i32), ("stride_w", c_i32),
                 ("head_w", c_void_p), ("head_b", c_void_p), ("head_out", c_void_p),
                 ("shared_chip", c_i32), ("post_mode", c_i32), ("post_res", c_void_p), ("n_dev", c_void_p),
-                ("in2", c_void_p), ("H2", c_i32), ("W2", c_i32), ("Cin2", c_i32), ("stride2", c_i32)]
+                ("in2", c_void_p), ("H2", c_i32), ("W2", c_i32), ("Cin2", c_i32), ("stride2", c_i32),
+                ("split_k", c_i32), ("split_ws", c_void_p)]
 
 
 class BottleneckParams(C.Structure):

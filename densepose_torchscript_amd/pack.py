@@ -49,6 +49,7 @@ class PackedConv:
         L.check(lib.dp_pack_conv_info(C.byref(p), C.byref(info)), "dp_pack_conv_info[%s]" % name)
         self.cin = cin_alloc
         self.cout, self.cout_w, self.kpad = info.cout, info.cout_w, info.kpad
+        self.split_k = 0      # > 1: dp_conv_params.split_k of this layer (PackedModel sets it for the long-K layers, see set_split_k)
         self.plane_major = bool(info.plane_major)
         wdt = {DP_F32: np.float32, DP_BF16: np.uint16, DP_F16: np.float16}[dtype]
         w_out = np.empty((self.cout_w, self.kpad), dtype=wdt)
@@ -172,6 +173,16 @@ def deconv_parity_convs(name, w_list, b_list, cin_alloc, dtype, device):
     return out
 
 
+def set_split_k(layer, segments):
+    """Mark a layer for split-K (dp_conv_params.split_k) when the kernels behind it take the layer: 16-bit storage, 64-byte K planes
+    inside one tap, Cout in 128-slices, at least two planes per segment. The value is fixed per LAYER - never per batch - so a
+    row's summation order does not depend on what else is in the batch."""
+    es = 4 if layer.dtype == DP_F32 else 2
+    planes = layer.kpad * es // 64
+    if layer.dtype != DP_F32 and (layer.cin * es) % 64 == 0 and layer.cout % 128 == 0 and planes >= 2 * segments:
+        layer.split_k = segments
+
+
 class PackedModel:
     def __init__(self, cfg, state, dtype, device):
         self.cfg = cfg
@@ -200,6 +211,8 @@ class PackedModel:
             # 64 -> 64 3x3 in 16-bit storage (the res2 blocks): tap-major K for the fused bottleneck tail
             L[p + "conv2"] = bnconv(p + "conv2", A8(cmid), 1, 1, plane_major=False if (cmid == 64 and dtype != DP_F32) else None)
             L[p + "conv3"] = bnconv(p + "conv3", A8(cmid), 1, 0)
+            if stage == "res5":
+                set_split_k(L[p + "conv2"], 3)     # 25 x 42 pixels per frame against K = 4608 (144 planes): three segments of 48
             # first block of res3 / res4 / res5 in the 16-bit modes: the projection shortcut as extra K planes of conv3 (one launch,
             # the shortcut tensor is never written or read back; fp32 parity mode keeps the reference's two convolutions + add)
             if sc and stage != "res2" and dtype != DP_F32 and A8(cmid) % 32 == 0 and A8(cin) % 32 == 0 and (A8(cmid) + A8(cin)) % 64 == 0:
@@ -239,6 +252,9 @@ class PackedModel:
         w1p = np.zeros((o, P, P, F), dtype=np.float32)
         w1p[..., : cfg.fpn_out] = w1
         L["fc1"] = linear_as_conv("fc1", w1p.reshape(o, P * P * F), st["roi_heads.box_head.fc1.bias"], P * P * F, dtype, device)
+        # K = 12544 (392 planes of 64 B) in two segments: batch 8 then fills the chip once with 256 x 256 tiles (0.199 -> 0.192 ms), a
+        # single frame's 1000 rows run 128 instead of 64 workgroups (0.151 -> 0.086 ms); four segments: 0.216 / 0.054 ms
+        set_split_k(L["fc1"], 2)
         fin = o
         for i in range(1, cfg.box_num_fc):
             n = "roi_heads.box_head.fc%d" % (i + 1)

@@ -37,7 +37,7 @@ enum dp_status {
   DP_ERR_LAUNCH = -3        /* hipGetLastError() after launch */
 };
 
-#define DP_ABI_VERSION 3
+#define DP_ABI_VERSION 4
 int dp_abi_version(void);
 /* human-readable reason of the last non-zero return on this thread */
 const char* dp_last_error(void);
@@ -128,6 +128,15 @@ typedef struct {
    * written nor read back. LDS-ring kernels only (DP_ERR_UNSUPPORTED otherwise). */
   const void* in2;
   int32_t H2, W2, Cin2, stride2;
+  /* Split-K (ABI 4): split_k > 1 cuts the K axis into split_k segments of whole 64-byte planes; workgroup (tile, segment) writes
+   * fp32 partial sums to split_ws ([split_k][N*Ho*Wo][Cout] floats, caller-owned scratch) and a second pass adds the segments in
+   * index order, then bias and activation. For layers with a long K and few pixel tiles (the box head's fc1: K = 12544 over 1000
+   * rows per image, box_head.py:60-67; res5's 3x3): one workgroup per tile streams megabytes of weights while most CUs idle. The
+   * value is a property of the LAYER: pass the same split_k whatever the batch, and a row's summation order - hence its bits -
+   * does not depend on what else is in the batch. 16-bit storage, LDS-ring kernels, plain NHWC output, no residual / head /
+   * second source / post_res / n_dev (DP_ERR_UNSUPPORTED otherwise). 0 or 1 = off. */
+  int32_t split_k;
+  void* split_ws;
 } dp_conv_params;
 int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
 /* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile,

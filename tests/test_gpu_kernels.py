@@ -569,6 +569,42 @@ def test_conv_pointwise_two_sources(eng, dt, shape, monkeypatch):
         assert err <= 2e-5 * max(ref.abs().max().item(), 1.0) * (c1 + c2) ** 0.5, (shape, force, err)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(1000, 1, 1, 12544, 1024, 1, 2), (5000, 1, 1, 12544, 1024, 1, 2), (1, 25, 42, 512, 512, 3, 3),
+                                   (8, 25, 42, 512, 512, 3, 3), (3, 9, 7, 128, 128, 3, 2), (37, 1, 1, 192, 256, 1, 3)])
+def test_conv_split_k(eng, dt, shape):
+    """dp_conv_params.split_k (the box head's fc1, box_head.py:60-67; res5's 3x3, resnet.py:195-197): K in segments of fp32 partial
+    sums + one reduction pass. Against torch in fp64, against the unsplit launch of the same layer, and - the point of fixing the
+    segment count per layer - bit for bit between a batch and any of its rows run alone (other tile shape, same segments)."""
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw, set_split_k
+    e = eng[dt]
+    N, H, W, cin, cout, k, seg = shape
+    g = torch.Generator().manual_seed(cin + cout + N)
+    x = _round(torch.randn((N, cin, H, W), generator=g), dt)
+    w = _round(torch.randn((cout, cin, k, k), generator=g) * (1.0 / (cin * k * k)) ** 0.5, dt)
+    b = torch.randn((cout,), generator=g)
+    layer = conv_from_oihw("t", w.numpy(), b.numpy(), cin, 1, k // 2, 1, e.dt, e.device)
+    set_split_k(layer, seg)
+    assert layer.split_k == seg
+    a = Act(_nhwc(x, cin, e.tdt, e.device), N, H, W, cin)
+    got = e.conv(layer, a, relu=True).t.float().cpu()
+    e.split_k_on = False
+    try:
+        plain = e.conv(layer, a, relu=True).t.float().cpu()
+    finally:
+        e.split_k_on = True
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=k // 2)).permute(0, 2, 3, 1)
+    scale = max(ref.abs().max().item(), 1.0)
+    tol = (2.0 ** -8 if dt == "bf16" else 2.0 ** -11) * scale + 2e-5 * scale * (cin * k * k) ** 0.5     # storage rounding + accumulation
+    assert (got.double() - ref).abs().max().item() <= tol
+    assert (got - plain).abs().max().item() <= (2.0 ** -7 if dt == "bf16" else 2.0 ** -10) * scale     # at most one step of the storage type apart
+    for n0, n1 in ((0, 1), (N // 2, N // 2 + max(1, N // 8))):
+        sub = e.conv(layer, Act(a.t[n0:n1].contiguous(), n1 - n0, H, W, cin), relu=True).t.float().cpu()
+        assert torch.equal(sub, got[n0:n1]), (shape, n0, n1)
+
+
 def test_conv_fpn_lateral_plus_nearest_upsample(eng):
     from densepose_torchscript_amd.engine import Act
     from densepose_torchscript_amd.pack import conv_from_oihw
