@@ -99,8 +99,8 @@ struct RpnPrepMulti {
 __global__ __launch_bounds__(kChunkThreads) void rpn_prep_kernel(const RpnPrepMulti pm) {
   __shared__ uint32_t keys[kChunk];
   __shared__ unsigned int hist[256];
-  __shared__ unsigned int sh_prefix, sh_need, sh_taken_gt, sh_taken_eq, sh_bucket_count;
-  __shared__ unsigned int wsum_gt[kChunkThreads / 64], wsum_eq[kChunkThreads / 64], pick_tot[4];
+  __shared__ unsigned int sh_prefix, sh_need, sh_bucket_count;
+  __shared__ unsigned int pick_tot[4];
   int lvl = 0;
   while (lvl + 1 < pm.n_levels && (int)blockIdx.x >= pm.first_block[lvl + 1]) ++lvl;
   const RpnPrepLevel& p = pm.lv[lvl];
@@ -126,7 +126,6 @@ __global__ __launch_bounds__(kChunkThreads) void rpn_prep_kernel(const RpnPrepMu
   uint32_t* okeys = cand_keys + ((long long)img * n_chunks + chunk) * kcap;
   uint32_t* oidx = cand_idx + ((long long)img * n_chunks + chunk) * kcap;
   const int kk = min(k, len);
-  if (tid == 0) { sh_taken_gt = 0; sh_taken_eq = 0; }
   __syncthreads();
   uint32_t T = 0;
   unsigned int need_eq = 0xffffffffu;  // len <= k: everything is kept (T = 0: all keys >= T, unlimited ties)
@@ -151,21 +150,48 @@ __global__ __launch_bounds__(kChunkThreads) void rpn_prep_kernel(const RpnPrepMu
     T = prefix;
     need_eq = need;
   }
-  // ordered compaction: position = (#kept before me); kept = key > T, or key == T while fewer than need_eq ties were taken
+  // ordered compaction: position = (#kept before me); kept = key > T, or key == T while fewer than need_eq ties were taken.
+  // Two sweeps instead of one with three barriers per 256 keys (that loop was most of the launch's 40 us): sweep 1 counts the kept
+  // and the tied keys of every (256-key slice, wave) pair, one scan of the 128 counts turns them into start positions, sweep 2
+  // recomputes the ballots and writes - no barrier inside either sweep.
   const int lane = tid & 63, w = tid >> 6;
-  for (int t0 = 0; t0 < len; t0 += kChunkThreads) {
-    const int t = t0 + tid;
+  constexpr int NIT = kChunk / kChunkThreads, NCNT = NIT * (kChunkThreads / 64);
+  static_assert(NCNT <= kChunkThreads && NCNT == 128, "one thread per (slice, wave) count, two waves of them");
+  __shared__ unsigned int cnt[NCNT];      // kept | tied << 16 (both <= 8192)
+  __shared__ unsigned int cnt_wave0;
+  const bool all = len <= kk;
+  for (int it = 0; it < NIT; ++it) {
+    const int t = it * kChunkThreads + tid;
     const uint32_t key = t < len ? keys[t] : 0u;
-    const bool gt = (t < len) && (len <= kk ? true : key > T);
-    const bool eq = (t < len) && !(len <= kk) && key == T;
+    const bool gt = (t < len) && (all ? true : key > T);
+    const bool eq = (t < len) && !all && key == T;
     const unsigned long long bg = __ballot(gt), be = __ballot(eq);
-    if (lane == 0) { wsum_gt[w] = (unsigned)__popcll(bg); wsum_eq[w] = (unsigned)__popcll(be); }
+    if (lane == 0) cnt[it * (kChunkThreads / 64) + w] = (unsigned)__popcll(bg) | ((unsigned)__popcll(be) << 16);
+  }
+  __syncthreads();
+  {
+    unsigned int own = tid < NCNT ? cnt[tid] : 0u, incl = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned int v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    if (tid == 63) cnt_wave0 = incl;
     __syncthreads();
-    unsigned int gt_before = sh_taken_gt, eq_before = sh_taken_eq;
-    for (int ww = 0; ww < w; ++ww) { gt_before += wsum_gt[ww]; eq_before += wsum_eq[ww]; }
+    if (tid < NCNT) cnt[tid] = incl - own + (w == 1 ? cnt_wave0 : 0u);     // exclusive prefix in (slice, wave) order
+  }
+  __syncthreads();
+  for (int it = 0; it < NIT; ++it) {
+    const int t = it * kChunkThreads + tid;
+    if (it * kChunkThreads >= len) break;
+    const uint32_t key = t < len ? keys[t] : 0u;
+    const bool gt = (t < len) && (all ? true : key > T);
+    const bool eq = (t < len) && !all && key == T;
+    const unsigned long long bg = __ballot(gt), be = __ballot(eq);
+    const unsigned int before = cnt[it * (kChunkThreads / 64) + w];
     const unsigned long long lm = (1ull << lane) - 1ull;
-    const unsigned int my_gt = gt_before + (unsigned)__popcll(bg & lm);
-    const unsigned int my_eq = eq_before + (unsigned)__popcll(be & lm);
+    const unsigned int my_gt = (before & 0xffffu) + (unsigned)__popcll(bg & lm);
+    const unsigned int my_eq = (before >> 16) + (unsigned)__popcll(be & lm);
     const bool take_eq = eq && my_eq < need_eq;
     if (gt || take_eq) {
       // ties already taken before me (capped at need_eq) + greater keys before me
@@ -173,14 +199,6 @@ __global__ __launch_bounds__(kChunkThreads) void rpn_prep_kernel(const RpnPrepMu
       okeys[pos] = key;
       oidx[pos] = (uint32_t)(i0 + t);
     }
-    __syncthreads();
-    if (tid == 0) {
-      unsigned int tg = 0, te = 0;
-      for (int ww = 0; ww < kChunkThreads / 64; ++ww) { tg += wsum_gt[ww]; te += wsum_eq[ww]; }
-      sh_taken_gt += tg;
-      sh_taken_eq += te;
-    }
-    __syncthreads();
   }
   // padding slots (chunks shorter than kcap): lowest key, sentinel index
   for (int t = kk + tid; t < kcap; t += kChunkThreads) { okeys[t] = 0u; oidx[t] = 0xffffffffu; }
@@ -202,6 +220,8 @@ struct RpnSelArgs {
 
 struct RpnSelMulti {
   RpnSelArgs lv[5];
+  int n2max;       // sort slots of the largest level: the key copy below starts behind them
+  int keys_cap;    // keys of a (image, level) that fit the LDS copy
 };
 
 __global__ __launch_bounds__(kSelThreads) void rpn_select_kernel(const RpnSelMulti pm) {
@@ -221,8 +241,15 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_kernel(const RpnSelMul
   const uint32_t* keys = p.keys + (long long)img * n;
   const uint32_t* kidx = p.kidx ? p.kidx + (long long)img * n : nullptr;
 #define DP_AIDX(i) (kidx ? kidx[i] : (uint32_t)(i))
+  // the keys are swept five to six times (four radix passes, the gather, the tie pass): one copy into LDS when they fit (the
+  // p2 level's 25 x 1000 chunk candidates do), each sweep then costs LDS reads instead of an L2 round trip per 1024 keys
+  uint32_t* const lkeys = reinterpret_cast<uint32_t*>(smem_raw + (size_t)pm.n2max * 8);
+  const bool in_lds = n > p.kmax && n <= pm.keys_cap;
+#define DP_KEY(i) (in_lds ? lkeys[i] : keys[i])
 
   for (int i = tid; i < n2; i += kSelThreads) sel[i] = 0ull;
+  if (in_lds)
+    for (int i = tid; i < n; i += kSelThreads) lkeys[i] = keys[i];
   if (tid == 0) { sh_count = 0; sh_eq_taken = 0; }
   __syncthreads();
 
@@ -236,7 +263,7 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_kernel(const RpnSelMul
       for (int i = tid; i < 256; i += kSelThreads) hist[i] = 0;
       __syncthreads();
       for (int i = tid; i < n; i += kSelThreads) {
-        const uint32_t key = keys[i];
+        const uint32_t key = DP_KEY(i);
         if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
       }
       __syncthreads();
@@ -252,7 +279,7 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_kernel(const RpnSelMul
     const unsigned int eq_total = sh_eq_total;
     // ---- gather keys > T (any order: they are sorted afterwards) ----
     for (int i = tid; i < n; i += kSelThreads) {
-      const uint32_t key = keys[i];
+      const uint32_t key = DP_KEY(i);
       if (key > T || (key == T && need_eq == eq_total)) {
         const unsigned int pos = atomicAdd(&sh_count, 1u);
         sel[pos] = ((unsigned long long)key << 32) | (uint32_t)(~DP_AIDX(i));
@@ -264,7 +291,7 @@ __global__ __launch_bounds__(kSelThreads) void rpn_select_kernel(const RpnSelMul
       const unsigned int base = sh_count;
       for (int i0 = 0; i0 < n; i0 += kSelThreads) {
         const int i = i0 + tid;
-        const bool f = (i < n) && (keys[i] == T);
+        const bool f = (i < n) && (DP_KEY(i) == T);
         const unsigned long long bal = __ballot(f);
         const int lane = tid & 63, w = tid >> 6;
         if (lane == 0) wave_sums[w] = (unsigned)__popcll(bal);
@@ -333,8 +360,10 @@ struct NmsWs {
   int32_t* sgroup;      // [n_img][n_slots]
   int32_t* sslot;       // [n_img][n_slots]
   int32_t* nvalid;      // [n_img] (+ padding)
+  int32_t* meta;        // [n_img][kNmsMeta]: [0] run mode, [1] runs, [2 .. 2 + runs] first sorted position of run r (and the end)
   unsigned long long* mask;  // [n_img][n_slots][ncb]
 };
+constexpr int kNmsMeta = 16;
 __host__ __device__ inline long long align256(long long x) { return (x + 255) & ~255ll; }
 inline NmsWs carve_nms_ws(void* ws, int n_img, int n_slots) {
   unsigned char* b = reinterpret_cast<unsigned char*>(ws);
@@ -344,6 +373,7 @@ inline NmsWs carve_nms_ws(void* ws, int n_img, int n_slots) {
   w.sgroup = reinterpret_cast<int32_t*>(b + off); off = align256(off + (long long)n_img * n_slots * 4);
   w.sslot = reinterpret_cast<int32_t*>(b + off); off = align256(off + (long long)n_img * n_slots * 4);
   w.nvalid = reinterpret_cast<int32_t*>(b + off); off = align256(off + (long long)n_img * 4);
+  w.meta = reinterpret_cast<int32_t*>(b + off); off = align256(off + (long long)n_img * kNmsMeta * 4);
   w.mask = reinterpret_cast<unsigned long long*>(b + off);
   return w;
 }
@@ -960,7 +990,14 @@ extern "C" int dp_rpn_topk_decode_levels(const dp_rpn_level_params* levels, int 
   pm.first_block[n_levels] = n_blocks;
   pm.n_levels = n_levels;
   hipLaunchKernelGGL(rpn_prep_kernel, dim3(n_blocks, levels[0].n_img), dim3(kChunkThreads), 0, s, pm);
-  hipLaunchKernelGGL(rpn_select_kernel, dim3(levels[0].n_img, n_levels), dim3(kSelThreads), n2max * 8, s, m);
+  m.n2max = n2max;
+  m.keys_cap = 25600;      // 100 KB
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rpn_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 8 + 25600 * 4);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(rpn_select_kernel, dim3(levels[0].n_img, n_levels), dim3(kSelThreads), n2max * 8 + m.keys_cap * 4, s, m);
   return dp_check_launch("rpn_select_kernel");
 }
 
@@ -976,6 +1013,7 @@ extern "C" int64_t dp_nms_workspace_bytes(int n_img, int n_slots) {
   off = align256(off + (long long)n_img * n_slots * 4);
   off = align256(off + (long long)n_img * n_slots * 4);
   off = align256(off + (long long)n_img * 4);
+  off = align256(off + (long long)n_img * kNmsMeta * 4);
   off = align256(off + (long long)n_img * n_slots * ncb * 8);
   return off;
 }
