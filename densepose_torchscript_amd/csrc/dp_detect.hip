@@ -360,10 +360,8 @@ struct NmsWs {
   int32_t* sgroup;      // [n_img][n_slots]
   int32_t* sslot;       // [n_img][n_slots]
   int32_t* nvalid;      // [n_img] (+ padding)
-  int32_t* meta;        // [n_img][kNmsMeta]: [0] run mode, [1] runs, [2 .. 2 + runs] first sorted position of run r (and the end)
   unsigned long long* mask;  // [n_img][n_slots][ncb]
 };
-constexpr int kNmsMeta = 16;
 __host__ __device__ inline long long align256(long long x) { return (x + 255) & ~255ll; }
 inline NmsWs carve_nms_ws(void* ws, int n_img, int n_slots) {
   unsigned char* b = reinterpret_cast<unsigned char*>(ws);
@@ -373,7 +371,6 @@ inline NmsWs carve_nms_ws(void* ws, int n_img, int n_slots) {
   w.sgroup = reinterpret_cast<int32_t*>(b + off); off = align256(off + (long long)n_img * n_slots * 4);
   w.sslot = reinterpret_cast<int32_t*>(b + off); off = align256(off + (long long)n_img * n_slots * 4);
   w.nvalid = reinterpret_cast<int32_t*>(b + off); off = align256(off + (long long)n_img * 4);
-  w.meta = reinterpret_cast<int32_t*>(b + off); off = align256(off + (long long)n_img * kNmsMeta * 4);
   w.mask = reinterpret_cast<unsigned long long*>(b + off);
   return w;
 }
@@ -1013,7 +1010,6 @@ extern "C" int64_t dp_nms_workspace_bytes(int n_img, int n_slots) {
   off = align256(off + (long long)n_img * n_slots * 4);
   off = align256(off + (long long)n_img * n_slots * 4);
   off = align256(off + (long long)n_img * 4);
-  off = align256(off + (long long)n_img * kNmsMeta * 4);
   off = align256(off + (long long)n_img * n_slots * ncb * 8);
   return off;
 }
