@@ -456,7 +456,10 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
   // wo * stride2). The plane's source is wave-uniform (its channel offset comes from the scalar tap table).
   constexpr bool dual = DUAL;
   const __amdgpu_buffer_rsrc_t rs_in2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dual ? p.in2 : p.in), 0, dual ? p.in2_bytes : 0u, 0x00020000);
-  int a_boff2[2] = {0, 0};
+  // a_dboff = (offset in the second source) - (offset in the first): the per-plane pick is a_boff + (a_dboff & mask) with a wave-uniform
+  // mask. Written as `src2 ? a_boff2[i] : a_boff[i]` hipcc merged the two arrays into ONE private array indexed by the uniform
+  // condition - 20 bytes of scratch and three scratch_load_dword per two K planes between the MFMAs of the steady loop (round 3).
+  int a_dboff[2] = {0, 0};
   if constexpr (dual) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
         const int rem = m - n * p.HoWo;
         const int ho = rem / p.Wo;
         const int wo = rem - ho * p.Wo;
-        a_boff2[i] = (((n * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.Cin2 + scc * CH) * ES;
+        a_dboff[i] = (((n * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.Cin2 + scc * CH) * ES - a_boff[i];
       }
     }
   }
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
     const int slot_ = ((S_IDX) & (kRing - 1)) * SLOT;                                                              \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
       if (i == 0 || a2) {                                                                                          \
-        const int off = (a_okm[i] & tapbit) ? ((src2_ ? a_boff2[i] : a_boff[i]) + tap_boff) : (int)0x80000000;     \
+        const int off = (a_okm[i] & tapbit) ? (a_boff[i] + (a_dboff[i] & (src2_ ? -1 : 0)) + tap_boff) : (int)0x80000000; \
         if (src2_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, DP_LDS_PTR(lds_sa + slot_ + i * NW * 1024), 16, off, 0, 0, 0); \
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(lds_sa + slot_ + i * NW * 1024), 16, off, 0, 0, 0); \
       }                                                                                                            \
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
             }
           } else if constexpr (m < 2) {
             if (m == 0 || a2) {
-              int off = (a_okm[m] & tapbit) ? ((src2 ? a_boff2[m] : a_boff[m]) + tap_boff) : (int)0x80000000;
+              int off = (a_okm[m] & tapbit) ? (a_boff[m] + (a_dboff[m] & (src2 ? -1 : 0)) + tap_boff) : (int)0x80000000;
               if constexpr (DP_RING_EXP & 2) off = lane * 16;     // diagnostic: same instruction count, one contiguous KiB per piece
               if (src2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in2, DP_LDS_PTR(lds_sa + dslot + m * NW * 1024), 16, off, 0, 0, 0);
               else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(lds_sa + dslot + m * NW * 1024), 16, off, 0, 0, 0);

@@ -89,3 +89,31 @@ def test_product_never_imports_oracle():
                 s = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M), f
                 assert "/root/reference" not in re.sub(r'""".*?"""', "", s, flags=re.S).replace("# ", ""), f
+
+
+def test_no_kernel_uses_scratch(built, tmp_path):
+    """No gfx950 kernel of the library spills or keeps a private array: zero scratch_ instructions in the disassembly and a
+    zero .private_segment_fixed_size in every kernel descriptor (round 3 shipped the two-source LDS-ring instances with 20 bytes
+    of scratch and scratch loads between the MFMAs of the steady loop)."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objdump, readelf = os.path.join(llvm, "llvm-objdump"), os.path.join(llvm, "llvm-readelf")
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("ROCm llvm tools not installed")
+    so = tmp_path / "lib.so"
+    shutil.copy(built.LIB_PATH, so)        # --offloading extracts the code objects beside its input
+    subprocess.check_call([objdump, "--offloading", str(so)], stdout=subprocess.DEVNULL, cwd=str(tmp_path))
+    objs = sorted(p for p in tmp_path.iterdir() if "amdgcn" in p.name)
+    assert objs, "no gfx950 code object found in %s" % built.LIB_PATH
+    n_kernels = 0
+    for o in objs:
+        dis = subprocess.check_output([objdump, "-d", str(o)]).decode()
+        bad = [ln for ln in dis.splitlines() if "scratch_" in ln]
+        assert not bad, (o.name, len(bad), bad[:3])
+        notes = subprocess.check_output([readelf, "--notes", str(o)]).decode()
+        sizes = re.findall(r"\.private_segment_fixed_size:\s*(\d+)", notes)
+        names = re.findall(r"\.name:\s*(\S+)", notes)
+        n_kernels += len(sizes)
+        assert sizes and all(int(s) == 0 for s in sizes), (o.name, [(n, s) for n, s in zip(names, sizes) if int(s)])
+    assert n_kernels > 100     # every template instance of every kernel was looked at
