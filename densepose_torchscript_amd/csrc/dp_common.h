@@ -124,6 +124,9 @@ __device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
 // dp_conv_ws.hip: the weight-stationary 3x3 kernel (128 -> 128 and 256 -> 256 channels) behind dp_conv2d_nhwc (kernel class 6)
 bool dp_conv_wsr_ok(const dp_conv_params* p);
 int dp_conv_wsr_launch(const dp_conv_params* p, dp_stream_t stream);
+// dp_conv_rows.hip: the row-streaming K-split weight-stationary 3x3 kernel (512 / 256 input channels) behind dp_conv2d_nhwc (kernel class 7)
+bool dp_conv_rows_ok(const dp_conv_params* p);
+int dp_conv_rows_launch(const dp_conv_params* p, dp_stream_t stream);
 
 // Packed weight matrices are stored in 1 KiB TILES of 16 rows x 64 bytes of K (round 3): tile (rg, plane) of a matrix with
 // n_planes = Kpad * esize / 64 K planes sits at ((rg * n_planes) + plane) * 1024, row-major inside. One LDS-DMA wave instruction (16

@@ -211,8 +211,8 @@ class PackedModel:
             # 64 -> 64 3x3 in 16-bit storage (the res2 blocks): tap-major K for the fused bottleneck tail
             L[p + "conv2"] = bnconv(p + "conv2", A8(cmid), 1, 1, plane_major=False if (cmid == 64 and dtype != DP_F32) else None)
             L[p + "conv3"] = bnconv(p + "conv3", A8(cmid), 1, 0)
-            if stage == "res5":
-                set_split_k(L[p + "conv2"], 3)     # 25 x 42 pixels per frame against K = 4608 (144 planes): three segments of 48
+            # (res5's 3x3 - 25 x 42 pixels per frame against K = 4608 - ran split-K in three segments in round 3; in the 16-bit modes it
+            # now runs on the row-streaming weight-stationary kernel, dp_conv_rows.hip, whatever the batch)
             # first block of res3 / res4 / res5 in the 16-bit modes: the projection shortcut as extra K planes of conv3 (one launch,
             # the shortcut tensor is never written or read back; fp32 parity mode keeps the reference's two convolutions + add)
             if sc and stage != "res2" and dtype != DP_F32 and A8(cmid) % 32 == 0 and A8(cin) % 32 == 0 and (A8(cmid) + A8(cin)) % 64 == 0:

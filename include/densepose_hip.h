@@ -141,7 +141,10 @@ typedef struct {
 int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
 /* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile,
  * 3 = 128x128 LDS-ring tile, 4 = 256x128 two-workgroup ring tile, 5 = streaming 1x1 (resident weights), 6 = weight-stationary 3x3
- * (128 -> 128 / 256 -> 256 channels, weights in registers) - profiling / roofline bookkeeping only */
+ * (128 -> 128 / 256 -> 256 channels, weights in registers), 7 = row-streaming K-split weight-stationary 3x3 (512 input channels, or
+ * 256 -> 512: the DensePose head v1convx.py:44-59 / deeplab.py:64-74 and res5's conv2 resnet.py:195-197; it honours n_dev by sizing
+ * its work from the live image count, and its per-pixel summation order - fixed, but not the other kernels' - is why a layer it
+ * takes runs on it for EVERY batch size) - profiling / roofline bookkeeping only */
 int dp_conv2d_kernel_class(const dp_conv_params* p);
 /* pixel rows of the tile dp_conv2d_nhwc will use for these parameters (the 256-cout ring kernel picks 128 .. 256 rows in
  * steps of 32 to fit the launch into whole rounds of the chip) - profiling / roofline bookkeeping only */

@@ -494,6 +494,74 @@ def test_conv3x3_weight_stationary_equals_ring_kernel(eng, dt, shape, monkeypatc
     assert bool(((gd - ref).abs() <= ulp * ref.abs() + 2e-3).all()), float((gd - ref).abs().max())
 
 
+ROWS_CASES = [
+    # Cin, Cout, N images, H, W, live images (None = all), relu
+    (512, 512, 8, 28, 28, None, True),      # DensePose head, v1convx.py:44-59 (two whole strip groups of four ROIs)
+    (512, 512, 7, 28, 28, 5, True),         # ragged group, device-side live count below N
+    (512, 512, 3, 28, 28, 0, True),         # R = 0: nothing live, nothing written
+    (512, 512, 1, 28, 28, None, False),     # one ROI (DeepLab head: no ReLU, deeplab.py:52)
+    (256, 512, 6, 28, 28, None, True),      # body_conv_fcn1: 256 -> 512
+    (256, 512, 9, 14, 14, 7, True),         # legacy pooler resolution: strips of 14 + 2
+    (512, 512, 2, 25, 42, None, True),      # res5 conv2 at 800 x 1344 (resnet.py:195-197): groups of eight images
+    (512, 512, 9, 25, 42, None, True),
+    (512, 512, 1, 1, 16, None, True),       # one row, one strip
+    (512, 512, 2, 2, 33, None, False),
+    (512, 64, 3, 5, 17, None, True),        # two cout slices only: more workgroups than rows
+    (256, 128, 2, 37, 48, None, True),
+    (512, 512, 70, 28, 28, 64, True),       # the benchmark's 64 ROIs inside a larger slot count
+]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", ROWS_CASES)
+def test_conv3x3_rows_kernel(eng, dt, case, monkeypatch):
+    """The row-streaming K-split weight-stationary 3x3 kernel (dp_conv_rows.hip, kernel class 7: the DensePose head's
+    body_conv_fcn1..8, v1convx.py:44-59 / deeplab.py:64-74, and res5's conv2, resnet.py:195-197) against torch in fp64 on operands
+    rounded to the storage type, against the LDS-ring kernel (same products, another summation order), and against itself image by
+    image: an image's result must not depend on what else is in the batch, on the strip group it lands in or on the device-side
+    live count."""
+    from densepose_torchscript_amd import lib as L
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    e = eng[dt]
+    Ci, Co, N, H, W, live, relu = case
+    monkeypatch.delenv("DP_CONV_ROWS", raising=False)
+    g = torch.Generator().manual_seed(Ci + Co + N * 1000 + H * 10 + W)
+    x = _round(torch.randn((N, Ci, H, W), generator=g), dt)
+    w = _round(torch.randn((Co, Ci, 3, 3), generator=g) * (1.0 / (9 * Ci)) ** 0.5, dt)
+    b = torch.randn((Co,), generator=g) * 0.3
+    layer = conv_from_oihw("fcn", w.numpy(), b.numpy(), Ci, 1, 1, 1, e.dt, e.device)
+    xa = Act(_nhwc(x, Ci, e.tdt, e.device), N, H, W, Ci)
+    p = L.ConvParams()
+    p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, Ci, H, W, Co, layer.cout_w, 9 * Ci
+    p.stride, p.ntaps, p.dtype, p.hi_off, p.wi_off = 1, 9, e.dt, -1, -1
+    p.osN, p.osH, p.osW = H * W * Co, W * Co, Co
+    p.out = 1
+    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 7
+    n_dev = None if live is None else torch.tensor([live], dtype=torch.int32, device=e.device)
+    nl = N if live is None else live
+    out = torch.full((N, H, W, Co), 7.0, dtype=e.tdt, device=e.device)      # slots behind the live count must stay untouched
+    got = e.conv(layer, xa, relu=relu, out=out, n_dev=n_dev)
+    torch.cuda.synchronize()
+    assert bool((got.t[nl:].float() == 7.0).all())
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = F.relu(ref) if relu else ref
+    ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    gd = got.t[:nl].float().cpu().permute(0, 3, 1, 2).double()
+    assert bool(((gd - ref[:nl]).abs() <= ulp * ref[:nl].abs() + 2e-3).all()), float((gd - ref[:nl]).abs().max())
+    # every image alone == the image inside the batch, bit for bit
+    for i in sorted({0, nl // 2, nl - 1} & set(range(nl))):
+        one = e.conv(layer, Act(xa.t[i:i + 1].contiguous(), 1, H, W, Ci), relu=relu)
+        assert torch.equal(one.t[0], got.t[i]), i
+    # the ring kernels on the same operands: equal up to the summation order
+    monkeypatch.setenv("DP_CONV_ROWS", "0")
+    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) != 7
+    want = e.conv(layer, xa, relu=relu)
+    torch.cuda.synchronize()
+    d = (want.t[:nl].float() - got.t[:nl].float()).abs()
+    assert bool((d <= 2 * ulp * want.t[:nl].float().abs() + 1e-3).all()), float(d.max())
+
+
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("shape", [(1, 50, 84), (2, 24, 46), (3, 30, 26), (1, 100, 168), (8, 14, 22)])
