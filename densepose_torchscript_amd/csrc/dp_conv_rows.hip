@@ -28,6 +28,11 @@
 #include "dp_mma.h"
 #include <stdlib.h>
 
+#ifndef DP_ROWS_EXP
+#define DP_ROWS_EXP 0     // diagnostic builds (timing only, results garbage): 1 no LDS-DMA in the loop, 2 no reduction, 4 no MFMAs, 8 no fragment reads,
+                          // 16 in-kernel phase stamps (s_memtime sums per wave, printed by the fifth launch)
+#endif
+
 namespace {
 
 int rows_num_cus() {
@@ -52,16 +57,8 @@ struct RowsArgs {
   int G, SPG;                  // images per strip group, strips per group (G * W == 16 * SPG)
   int n_slices, n_pg;          // cout slices, pixel groups (grid = n_slices * n_pg workgroups)
   unsigned in_bytes, out_bytes;
+  unsigned long long* dbg;     // diagnostic builds (-DDP_ROWS_EXP=16): per-wave phase cycle sums
 };
-
-// Compiler-level fence that eight VGPR values pass through: memory operations stay on their side of it and the values must exist
-// when it is reached. Device pass only: "v" is no x86 register constraint, and a kernel body the HOST pass cannot parse is dropped
-// without a diagnostic - the library then fails to load with the kernel's host stub undefined.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define DP_ROWS_PIN8(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : : "memory")
-#else
-#define DP_ROWS_PIN8(a) ((void)0)
-#endif
 
 template <int N>
 __device__ __forceinline__ void rows_wait_vm() {
@@ -90,7 +87,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const RowsArgs p) 
   constexpr int ROWB = NP * 1024;
   constexpr int D = 3, NSLOT = D + 1;           // rows in flight ahead of the one being consumed
   constexpr int RING = 8 * NSLOT * ROWB;
-  constexpr int NU = NCT / 2;                   // reduction units of 32 couts per finished row
   constexpr int STGB = 8 * NCT * 1024;          // staging bytes per parity: [wave][cout tile][lane] x 16 B
   constexpr int NF = NCB * 3;                   // pixel fragments per step: (channel block, column tap)
   constexpr int OOB = (int)0x80000000;
@@ -128,12 +124,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const RowsArgs p) 
               *reinterpret_cast<const u32x4*>(wp + dp_wtile_off(slice * NCT * 16 + ct * 16 + fr, (wave * NCB + cbl) * 9 + t, fq, n_planes));
   }
   const int cout0 = slice * NCT * 16;           // logical cout base of the slice
-  const int unit = NU == 1 ? 0 : (wave & 1);    // the reduction unit this wave takes when it is its turn
-  // the slice's bias waits in LDS behind the staging buffers (8 registers less in a kernel that sits at the 256-register line)
-  float* const bias_s = reinterpret_cast<float*>(smem + RING + 2 * STGB);
-  if (tid < NCT * 16) bias_s[tid] = p.bias[cout0 + tid];
-  __syncthreads();
-
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
   const int in_row = p.W * CIN * 2, out_row = p.W * p.opitch * 2;
@@ -168,24 +158,41 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const RowsArgs p) 
     }
   };
   unsigned char* const ring_w = smem + wave * (NSLOT * ROWB);
-  auto fetch = [&](const RowsIt& it, bool live, int slot) __attribute__((always_inline)) {
+  auto fetch = [&](const RowsIt& it, bool live, int slot, bool issue) __attribute__((always_inline)) {
     const bool row_ok = live && (unsigned)it.q < (unsigned)p.H;     // rows -1 and H are zero padding: nothing is read (nor computed)
     const int roff = it.q * in_row;
 #pragma unroll
     for (int pc = 0; pc < NP; ++pc)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(ring_w + slot * ROWB + pc * 1024), 16, row_ok ? f_boff[pc] + roff : OOB, 0, 0, 0);
+      if (issue)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(ring_w + slot * ROWB + pc * 1024), 16, row_ok ? f_boff[pc] + roff : OOB, 0, 0, 0);
   };
 
   // ---- compute side: lane (fr, fq) = output pixel fr of the strip; its staged pixel at column tap dx is fr + dx (+ 1 in the
   // second segment, behind the shared zero pixel)
-  int c_frag = 0, c_obase = OOB;
+  // ---- reduce side (waves 4 .. 7): lane l adds up the eight partial sums of TWO consecutive output channels of pixel (l & 31) >> 1:
+  // 32 lanes read 256 contiguous bytes of a partial tile (ds_read_b64, conflict free), wave 4 + j takes the cout tiles
+  // (j & 1) * ND .. + ND - 1 and the channel octets fq = 2 * (j >> 1) + (l >> 5) of every pixel.
+  constexpr int ND = NCT / 2;                    // reduction duties (cout tiles) per reducing wave
+  const bool is_y = wave >= 4;
+  const int rj = wave & 3;
+  const int r_px = (lane & 31) >> 1, r_fq = 2 * (rj >> 1) + (lane >> 5), r_half = lane & 1;
+  const int r_ct0 = (rj & 1) * ND;
+  const int r_lds = (r_fq * 16 + r_px) * 16 + r_half * 8;                 // byte of this lane's pair inside a [64 lanes x 16 B] partial tile
+  float r_bias[ND][2];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) {
+    const int ct = r_ct0 + d, co = cout0 + (ct >> 1) * 32 + r_fq * 8 + (ct & 1) * 4 + r_half * 2;
+    r_bias[d][0] = p.bias[co];
+    r_bias[d][1] = p.bias[co + 1];
+  }
+  int c_frag = 0, r_obase = OOB;
   auto setup_comp = [&](int strip) __attribute__((always_inline)) {
     int img0, c00, len0;
     decode(strip, img0, c00, len0);
-    const bool in1 = fr >= len0;
-    c_frag = (fr + (in1 ? 1 : 0)) * PPW + fq * 16;
-    const int img = img0 + (in1 ? 1 : 0), col = in1 ? fr - len0 : c00 + fr;
-    c_obase = img < n_live ? ((img * p.H * p.W + col) * p.opitch + cout0 + unit * 32 + fq * 8) * 2 : OOB;
+    c_frag = (fr + (fr >= len0 ? 1 : 0)) * PPW + fq * 16;
+    const bool in1 = r_px >= len0;
+    const int img = img0 + (in1 ? 1 : 0), col = in1 ? r_px - len0 : c00 + r_px;
+    r_obase = img < n_live ? ((img * p.H * p.W + col) * p.opitch + cout0 + r_fq * 8 + r_half * 2) * 2 : OOB;
   };
 
   auto seg_init = [&](RowsIt& it, int strip) __attribute__((always_inline)) {
@@ -202,12 +209,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const RowsArgs p) 
   seg_init(it_c, s_first);
   setup_fetch(s_first);
   setup_comp(s_first);
-  // prologue: the first D rows
   int f_done = 0;     // steps whose fetch has been issued
   auto fetch_next = [&]() __attribute__((always_inline)) {
     const bool live = f_done < n_steps;
     int slot = f_done % NSLOT;
-    fetch(it_f, live, slot);
+    fetch(it_f, live, slot, !(DP_ROWS_EXP & 1) || f_done < D);
     ++f_done;
     if (live) {
       if (it_f.q == it_f.r_hi) {
@@ -217,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const RowsArgs p) 
       }
     }
   };
+  // prologue: the first D rows
 #pragma unroll
   for (int d = 0; d < D; ++d) fetch_next();
 
@@ -227,122 +234,191 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const RowsArgs p) 
     for (int ct = 0; ct < NCT; ++ct) acc[a][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   unsigned char* const stg = smem + RING;
-  int ec = 0;          // emitted rows so far: staging parity and whose turn the reduction is
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tl = (DP_ROWS_EXP & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+#define DP_STAMP(k) if constexpr (DP_ROWS_EXP & 16) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - tl; tl = t_; }
 
-  // one step with the accumulator roles fixed at compile time: old = acc[(PH + 2) % 3] (output row q - 1, kernel row 2, complete after
-  // this step), mid = acc[PH] (row q, kernel row 1), fresh = acc[(PH + 1) % 3] (row q + 1, kernel row 0, starts from zero)
-  auto step = [&](auto ph_c, int s) __attribute__((always_inline)) {
-    constexpr int PH = decltype(ph_c)::value;
-    constexpr int A_OLD = (PH + 2) % 3, A_MID = PH, A_NEW = (PH + 1) % 3;
-    fetch_next();                                  // row of step s + D -> the slot step s - 1 has just finished reading
-    rows_wait_vm<NP * D>();                        // ... and the row of step s has landed (only the D younger rows may be in flight)
-    const int t = it_c.q - 1;                      // the output row that is complete after this step
-    const bool emit = t >= it_c.r_lo;
-    unsigned char* const sw = stg + (ec & 1) * STGB + wave * (NCT * 1024) + lane * 16;
-    const bool row_ok = (unsigned)it_c.q < (unsigned)p.H;
-    // Three passes over the step's fragments, one per accumulator role, the finished row first: its partial sums go to the staging
-    // buffer before the fresh row's accumulators are born, so only two of the three sets are live at any time (NCT = 4: 32 instead
-    // of 48 registers in a kernel that sits at the 256-register line). Per output pixel the order of the products is unchanged.
-    u32x4 bf[NF];
-    if (row_ok) {
-      const unsigned char* const row = ring_w + (s % NSLOT) * ROWB + c_frag;
-      static_for<0, NF>([&](auto ff) {
-        constexpr int f = decltype(ff)::value;
-        bf[f] = *reinterpret_cast<const u32x4*>(row + (f % 3) * PPW + (f / 3) * 64);
-      });
-      __builtin_amdgcn_sched_barrier(0);
-      static_for<0, NF>([&](auto ff) {
-        constexpr int f = decltype(ff)::value;
+  // the finished row of a step: eight partial tiles per cout tile in staging buffer `par` -> bias, activation, 4-byte stores
+  auto reduce = [&](int par, int t, int obase) __attribute__((always_inline)) {
+    if constexpr (DP_ROWS_EXP & 2) return;
+    const unsigned char* const sr = stg + par * STGB + r_lds;
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) Mma<T>::run(wfr[(ct * NCB + f / 3) * 9 + 6 + f % 3], bf[f], acc[A_OLD][ct]);
-      });
-    }
-    if (emit) {
+    for (int d = 0; d < ND; ++d) {
+      const int ct = r_ct0 + d;
+      f32x2 v[8];
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(sw + ct * 1024) = acc[A_OLD][ct];
-    }
-    __builtin_amdgcn_sched_barrier(0);
+      for (int w8 = 0; w8 < 8; ++w8) v[w8] = *reinterpret_cast<const f32x2*>(sr + (w8 * NCT + ct) * 1024);
+      float x0 = v[0][0], x1 = v[0][1];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) acc[A_NEW][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row_ok) {
-      static_for<0, NF>([&](auto ff) {
-        constexpr int f = decltype(ff)::value;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) Mma<T>::run(wfr[(ct * NCB + f / 3) * 9 + 3 + f % 3], bf[f], acc[A_MID][ct]);
-      });
-      static_for<0, NF>([&](auto ff) {
-        constexpr int f = decltype(ff)::value;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) Mma<T>::run(wfr[(ct * NCB + f / 3) * 9 + 0 + f % 3], bf[f], acc[A_NEW][ct]);
-      });
-    }
-    if (emit) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      const bool my_turn = NU == 1 ? (wave == (ec & 7)) : ((wave >> 1) == (ec & 3));
-      if (my_turn) {
-        const unsigned char* const sr = stg + (ec & 1) * STGB + unit * 2048 + lane * 16;
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = 0.f;
-        // two partials (four reads) in flight at a time: left alone the scheduler issues all 16 reads first and keeps their 64
-        // registers live to the end (a sched_barrier does not stop it; a compiler-level fence that ALL eight running sums pass
-        // through does) - the kernel sits at the 256-register line and spilled weight fragments
-#pragma unroll
-        for (int w8 = 0; w8 < 8; w8 += 2) {
-          const f32x4 lo0 = *reinterpret_cast<const f32x4*>(sr + w8 * (NCT * 1024));
-          const f32x4 hi0 = *reinterpret_cast<const f32x4*>(sr + w8 * (NCT * 1024) + 1024);
-          const f32x4 lo1 = *reinterpret_cast<const f32x4*>(sr + (w8 + 1) * (NCT * 1024));
-          const f32x4 hi1 = *reinterpret_cast<const f32x4*>(sr + (w8 + 1) * (NCT * 1024) + 1024);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) { v[k] += lo0[k]; v[4 + k] += hi0[k]; }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) { v[k] += lo1[k]; v[4 + k] += hi1[k]; }
-          DP_ROWS_PIN8(v);
-        }
-        const f32x4 bz0 = *reinterpret_cast<const f32x4*>(bias_s + unit * 32 + fq * 8), bz1 = *reinterpret_cast<const f32x4*>(bias_s + unit * 32 + fq * 8 + 4);
-        u32x4 pk;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float x0 = v[2 * k] + (k < 2 ? bz0[2 * k] : bz1[2 * k - 4]), x1 = v[2 * k + 1] + (k < 2 ? bz0[2 * k + 1] : bz1[2 * k - 3]);
-          if (p.relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
-          pk[k] = Elem<T>::pack2(x0, x1);
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, c_obase + t * out_row, 0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      ++ec;
-    }
-    // next step of the compute walk
-    if (it_c.q == it_c.r_hi) {
-      if (it_c.strip < s_last) { seg_init(it_c, it_c.strip + 1); setup_comp(it_c.strip); }
-    } else {
-      ++it_c.q;
+      for (int w8 = 1; w8 < 8; ++w8) { x0 += v[w8][0]; x1 += v[w8][1]; }     // wave order: the summation order of a pixel is fixed
+      x0 += r_bias[d][0];
+      x1 += r_bias[d][1];
+      if (p.relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+      __builtin_amdgcn_raw_buffer_store_b32(Elem<T>::pack2(x0, x1), rs_out, obase + t * out_row + ((ct >> 1) * 32 + (ct & 1) * 4) * 2, 0, 0);
+      asm volatile("" ::: "memory");     // one duty's eight reads in flight at a time (registers)
     }
   };
 
-  int s = 0;
-  for (; s + 3 <= n_steps; s += 3) {
-    step(std::integral_constant<int, 0>{}, s);
-    step(std::integral_constant<int, 1>{}, s + 1);
-    step(std::integral_constant<int, 2>{}, s + 2);
+  // Phase A of step s (no matrix instruction): bookkeeping, the row fetch D steps ahead, the reduction of the row the previous step
+  // finished (waves 4 .. 7), the fragment reads of this step's row. Phase B: the step's MFMAs and its partial sums -> staging.
+  // Waves 4 .. 7 run ONE BARRIER behind waves 0 .. 3, so on every SIMD one wave is in its phase B while its partner is in phase A.
+  u32x4 bf[NF];
+  // what the two previous steps left to reduce: the row of step s - 2 is complete in the staging buffer when phase A of step s starts
+  bool p1_emit = false, p2_emit = false;
+  int p1_t = 0, p2_t = 0, p1_ob = OOB, p2_ob = OOB;
+  auto phase_a = [&](int s) __attribute__((always_inline)) {
+    DP_STAMP(7)
+    if (s > 0) {
+      p2_emit = p1_emit; p2_t = p1_t; p2_ob = p1_ob;
+      p1_t = it_c.q - 1;
+      p1_emit = p1_t >= it_c.r_lo;
+      p1_ob = r_obase;
+      if (it_c.q == it_c.r_hi) {       // on to this step's row
+        if (it_c.strip < s_last) { seg_init(it_c, it_c.strip + 1); setup_comp(it_c.strip); }
+      } else {
+        ++it_c.q;
+      }
+    }
+    fetch_next();                                  // row of step s + D -> the slot step s - 1 has finished reading
+    DP_STAMP(0)
+    if (s >= 2 && p2_emit && (((s - 2) & 1) != 0) == is_y) reduce((s - 2) % 3, p2_t, p2_ob);
+    DP_STAMP(1)
+    if (!(DP_ROWS_EXP & 1)) rows_wait_vm<NP * D>(); // the row of step s has landed (only the D younger rows - and this phase's stores - may be in flight)
+    if ((unsigned)it_c.q < (unsigned)p.H) {
+      const unsigned char* const row = ring_w + (s % NSLOT) * ROWB + c_frag;
+      static_for<0, NF>([&](auto ff) {
+        constexpr int f = decltype(ff)::value;
+        if constexpr (DP_ROWS_EXP & 8) bf[f] = u32x4{(unsigned)lane, (unsigned)f, 1u, 2u};
+        else bf[f] = *reinterpret_cast<const u32x4*>(row + (f % 3) * PPW + (f / 3) * 64);
+      });
+    }
+    DP_STAMP(2)
+  };
+  // accumulator roles fixed at compile time: old = acc[(PH + 2) % 3] (output row q - 1, kernel row 2, complete after this step),
+  // mid = acc[PH] (row q, kernel row 1), fresh = acc[(PH + 1) % 3] (row q + 1, kernel row 0, starts from zero). Three passes over the
+  // step's fragments, one per role, the finished row first: its partial sums go to the staging buffer before the fresh row's
+  // accumulators are born, so only two of the three sets are live at any time. Per output pixel the order of the products is
+  // kernel row, 32-channel block, kernel column.
+  auto phase_b = [&](auto ph_c, int s) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph_c)::value;
+    constexpr int A_OLD = (PH + 2) % 3, A_MID = PH, A_NEW = (PH + 1) % 3;
+    const bool emit = it_c.q - 1 >= it_c.r_lo;
+    const bool row_ok = (unsigned)it_c.q < (unsigned)p.H;
+    unsigned char* const sw = stg + (s % 3) * STGB + wave * (NCT * 1024) + lane * 16;
+    auto mma = [&](auto ff, auto ky_c, f32x4 (&a)[NCT]) __attribute__((always_inline)) {
+      constexpr int f = decltype(ff)::value, ky = decltype(ky_c)::value;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        if constexpr (DP_ROWS_EXP & 4) { if (ct == 0) a[0][0] += __builtin_bit_cast(float, bf[f][0]); }
+        else if constexpr (DP_ROWS_EXP & 32) Mma<T>::run(wfr[ct], bf[f], a[ct]);     // diagnostic: the same A operand for every MFMA of a cout tile
+        else Mma<T>::run(wfr[(ct * NCB + f / 3) * 9 + ky * 3 + f % 3], bf[f], a[ct]);
+      }
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[A_NEW][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_setprio(1);      // the wave in its matrix phase goes first; its partner is in phase A
+    if constexpr (NCT >= 4) {
+      // three passes over the step's fragments, one per role, the finished row first: its partial sums leave for the staging buffer
+      // before the fresh row's accumulators are born - two of the three sets live at a time (32 instead of 48 registers)
+      if (row_ok) static_for<0, NF>([&](auto ff) { mma(ff, K2{}, acc[A_OLD]); });
+      if (emit) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(sw + ct * 1024) = acc[A_OLD][ct];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (row_ok) {
+        static_for<0, NF>([&](auto ff) { mma(ff, K1{}, acc[A_MID]); });
+        static_for<0, NF>([&](auto ff) { mma(ff, K0{}, acc[A_NEW]); });
+      }
+    } else {
+      // two cout tiles: the three roles interleaved per fragment, so that an accumulator is touched by every SIXTH matrix
+      // instruction. One pass per role touched it every second one - and a wave alone on the matrix pipe then issued an MFMA every
+      // ~24 cycles instead of every 16 (phase stamps: 36 MFMAs in 860 cycles): the result of an 8-pass MFMA is not back as a source
+      // two instructions later.
+      if (row_ok) static_for<0, NF>([&](auto ff) { mma(ff, K2{}, acc[A_OLD]); mma(ff, K1{}, acc[A_MID]); mma(ff, K0{}, acc[A_NEW]); });
+      if (emit) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(sw + ct * 1024) = acc[A_OLD][ct];
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (DP_ROWS_EXP & 16) asm volatile("s_nop 0" :: "v"(acc[A_NEW][NCT - 1][0]), "v"(acc[A_MID][NCT - 1][0]));
+    DP_STAMP(4)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the partial sums are in the staging buffer before the barrier
+    DP_STAMP(5)
+  };
+
+  // unrolled by the three accumulator roles (a run-time role would keep all three sets live across the loop edge). ONE barrier per
+  // step, and it sits in a different place for the two halves of the workgroup: waves 0 .. 3 run A B | A B | ..., waves 4 .. 7
+  // A | B A | B A | ... - between two barriers a SIMD's older wave goes A -> B while its partner goes B -> A.
+  auto unit = [&](auto ph_c, int s) __attribute__((always_inline)) {
+    phase_a(s);
+    if (is_y) { __builtin_amdgcn_s_barrier(); DP_STAMP(3) }
+    phase_b(ph_c, s);
+    if (!is_y) { __builtin_amdgcn_s_barrier(); DP_STAMP(6) }
+  };
+  for (int s = 0; s < n_steps; s += 3) {
+    unit(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < n_steps) unit(std::integral_constant<int, 1>{}, s + 1);
+    if (s + 2 < n_steps) unit(std::integral_constant<int, 2>{}, s + 2);
   }
-  if (s < n_steps) step(std::integral_constant<int, 0>{}, s);
-  if (s + 1 < n_steps) step(std::integral_constant<int, 1>{}, s + 1);
+  __builtin_amdgcn_s_barrier();                  // waves 4 .. 7 have written the last step's partial sums
+  {
+    // the rows of the last two steps (it_c still stands on the last step)
+    const int tl_ = it_c.q - 1;
+    if (n_steps >= 2 && p1_emit && (((n_steps - 2) & 1) != 0) == is_y) reduce((n_steps - 2) % 3, p1_t, p1_ob);
+    if (tl_ >= it_c.r_lo && (((n_steps - 1) & 1) != 0) == is_y) reduce((n_steps - 1) % 3, tl_, r_obase);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy fetches behind the last step still target this workgroup's LDS
+  if constexpr (DP_ROWS_EXP & 16) {
+    if (lane == 0 && p.dbg) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p.dbg[(blockIdx.x * 8 + wave) * 16 + k] = ph[k];
+      p.dbg[(blockIdx.x * 8 + wave) * 16 + 8] = n_steps;
+    }
+  }
+#undef DP_STAMP
 }
 
 template <typename T, int CIN, int NCT>
 int launch_rows_r(const RowsArgs& a, hipStream_t stream) {
   constexpr int KPW = CIN / 8, PPW = KPW * 2 + 32, NP = (19 * PPW + 1023) / 1024;
-  constexpr int lds = 8 * 4 * NP * 1024 + 2 * 8 * NCT * 1024 + NCT * 16 * 4;
+  constexpr int lds = 8 * 4 * NP * 1024 + 3 * 8 * NCT * 1024;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_rows_kernel<T, CIN, NCT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
+#if DP_ROWS_EXP & 16
+  RowsArgs b = a;
+  static unsigned long long* dbg = nullptr;
+  const int nblk = a.n_pg * a.n_slices;
+  if (!dbg) (void)hipMalloc(&dbg, sizeof(unsigned long long) * 8 * 16 * 4096);
+  b.dbg = dbg;
+  (void)hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 8 * 16 * nblk, stream);
+  hipLaunchKernelGGL((conv3x3_rows_kernel<T, CIN, NCT>), dim3(nblk), dim3(512), lds, stream, b);
+  {
+    static int shown = 0;
+    if (shown++ == 4) {   // a warm launch
+      (void)hipStreamSynchronize(stream);
+      unsigned long long* hb = (unsigned long long*)malloc(sizeof(unsigned long long) * 128 * nblk);
+      (void)hipMemcpy(hb, dbg, sizeof(unsigned long long) * 128 * nblk, hipMemcpyDeviceToHost);
+      for (int w = 0; w < 8; ++w) {
+        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n = 0;
+        for (int bb = 0; bb < nblk; ++bb) { for (int k = 0; k < 8; ++k) sum[k] += (double)hb[(bb * 8 + w) * 16 + k]; n += (double)hb[(bb * 8 + w) * 16 + 8]; }
+        fprintf(stderr, "rows wave %d: cycles per step: A: fetch issue %.0f  reduce %.0f  vmcnt wait + read issue %.0f  barrier (waves 4-7) %.0f | B: mfma + staging write %.0f  lgkm wait %.0f  barrier (waves 0-3) %.0f | bookkeeping %.0f  (steps/wg %.1f)\n",
+                w, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n, sum[6] / n, sum[7] / n, n / nblk);
+      }
+      free(hb);
+    }
+  }
+#else
   hipLaunchKernelGGL((conv3x3_rows_kernel<T, CIN, NCT>), dim3(a.n_pg * a.n_slices), dim3(512), lds, stream, a);
+#endif
   return dp_check_launch("conv3x3_rows_kernel");
 }
 
@@ -352,6 +428,17 @@ int launch_rows(const RowsArgs& a, int cin, hipStream_t stream) {
 }
 
 int gcd_i(int a, int b) { return b == 0 ? a : gcd_i(b, a % b); }
+
+// every strip of a group of G = 16 / gcd(W, 16) images is at most two segments from two consecutive images
+bool rows_width_ok(int W) {
+  if (W < 8) return false;
+  const int G = 16 / gcd_i(W, 16), spg = G * W / 16;
+  for (int k = 0; k < spg; ++k) {
+    const int c00 = (16 * k) % W, len0 = W - c00 < 16 ? W - c00 : 16;
+    if (16 - len0 > W) return false;
+  }
+  return true;
+}
 
 }  // namespace
 
@@ -364,7 +451,7 @@ bool dp_conv_rows_ok(const dp_conv_params* p) {
   const bool shape = (p->Cin == 512 && p->Cout % 32 == 0) || (p->Cin == 256 && p->Cout % 64 == 0 && (mode == 2 || p->Cout == 512));
   const int g = 16 / gcd_i(p->W > 0 ? p->W : 16, 16);
   return (p->dtype == DP_BF16 || p->dtype == DP_F16) && shape && p->ntaps == 9 && p->Kpad == 9 * p->Cin && p->stride == 1 &&
-         (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == -1 && p->wi_off == -1 && p->H == p->Ho && p->W == p->Wo && p->W >= 16 &&
+         (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == -1 && p->wi_off == -1 && p->H == p->Ho && p->W == p->Wo && rows_width_ok(p->W) &&
          !p->residual && !p->out_f32 && !p->head_out && !p->in2 && !p->post_res && p->post_mode == 0 && p->split_k <= 1 && p->out &&
          p->osW >= p->Cout && p->osW % 8 == 0 && p->osH == (long long)p->W * p->osW && p->osN == (long long)p->H * p->W * p->osW &&
          p->Cout <= p->Cout_w && p->Cout_w % 64 == 0 &&
@@ -382,6 +469,7 @@ int dp_conv_rows_launch(const dp_conv_params* p, dp_stream_t stream) {
   int groups = rows_num_cus() / (8 * a.n_slices);
   if (groups < 1) groups = 1;
   a.n_pg = groups * 8;
+  a.dbg = nullptr;
   a.in_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cin * 2);
   a.out_bytes = (unsigned)((long long)p->N * p->H * p->W * p->osW * 2);
   hipStream_t s = as_stream(stream);

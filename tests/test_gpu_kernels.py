@@ -506,8 +506,8 @@ ROWS_CASES = [
     (512, 512, 9, 25, 42, None, True),
     (512, 512, 1, 1, 16, None, True),       # one row, one strip
     (512, 512, 2, 2, 33, None, False),
-    (512, 64, 3, 5, 17, None, True),        # two cout slices only: more workgroups than rows
-    (256, 128, 2, 37, 48, None, True),
+    (512, 96, 3, 5, 17, None, True),        # three cout slices only: more workgroups than rows
+    (256, 512, 2, 37, 48, None, True),
     (512, 512, 70, 28, 28, 64, True),       # the benchmark's 64 ROIs inside a larger slot count
 ]
 
