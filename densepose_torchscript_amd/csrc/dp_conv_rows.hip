@@ -445,10 +445,14 @@ bool rows_width_ok(int W) {
 // used by dp_conv2d_nhwc (dp_conv.hip): is this launch a 3x3 / pad 1 / stride 1 layer the kernel is written for? No size thresholds:
 // the kernel's summation order differs from the LDS-ring kernels', so a layer either always runs here or never (batch invariance).
 bool dp_conv_rows_ok(const dp_conv_params* p) {
-  const char* e = getenv("DP_CONV_ROWS");    // A/B knob: 0 keeps these layers on the other kernels; 2 also takes the 256-channel layers
+  // Default (mode 1): the 512-channel layers on plain tensors - res5's conv2, 45 us against 60 - 64 on the LDS-ring kernels at batch 8.
+  // Launches sized on the device (n_dev: the DensePose head on R x 28 x 28 ROI maps) stay on the ring kernel: measured at par there
+  // (profiles/r4_rows_kernel_experiments.txt), and which kernel a call site takes must not depend on the batch - n_dev is a property
+  // of the call site. A/B knob DP_CONV_ROWS: 0 never, 2 also the n_dev launches and the 256 -> 512 layer.
+  const char* e = getenv("DP_CONV_ROWS");
   const int mode = e ? atoi(e) : 1;
-  if (mode == 0) return false;
-  const bool shape = (p->Cin == 512 && p->Cout % 32 == 0) || (p->Cin == 256 && p->Cout % 64 == 0 && (mode == 2 || p->Cout == 512));
+  if (mode == 0 || (mode != 2 && p->n_dev != nullptr)) return false;
+  const bool shape = (p->Cin == 512 && p->Cout % 32 == 0) || (p->Cin == 256 && p->Cout % 64 == 0 && mode == 2);
   const int g = 16 / gcd_i(p->W > 0 ? p->W : 16, 16);
   return (p->dtype == DP_BF16 || p->dtype == DP_F16) && shape && p->ntaps == 9 && p->Kpad == 9 * p->Cin && p->stride == 1 &&
          (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == -1 && p->wi_off == -1 && p->H == p->Ho && p->W == p->Wo && rows_width_ok(p->W) &&

@@ -525,7 +525,7 @@ def test_conv3x3_rows_kernel(eng, dt, case, monkeypatch):
     from densepose_torchscript_amd.pack import conv_from_oihw
     e = eng[dt]
     Ci, Co, N, H, W, live, relu = case
-    monkeypatch.delenv("DP_CONV_ROWS", raising=False)
+    monkeypatch.setenv("DP_CONV_ROWS", "2")     # every shape the kernel takes (default policy: 512 input channels, no device-side count)
     g = torch.Generator().manual_seed(Ci + Co + N * 1000 + H * 10 + W)
     x = _round(torch.randn((N, Ci, H, W), generator=g), dt)
     w = _round(torch.randn((Co, Ci, 3, 3), generator=g) * (1.0 / (9 * Ci)) ** 0.5, dt)
@@ -539,6 +539,13 @@ def test_conv3x3_rows_kernel(eng, dt, case, monkeypatch):
     p.out = 1
     assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 7
     n_dev = None if live is None else torch.tensor([live], dtype=torch.int32, device=e.device)
+    # the default policy: a call site is on this kernel for every batch or for none - 512-channel layers on plain tensors (res5's conv2)
+    # are, launches sized on the device (the DensePose head) and the 256 -> 512 layer are not
+    monkeypatch.delenv("DP_CONV_ROWS")
+    p.n_dev = None if n_dev is None else n_dev.data_ptr()
+    assert (e.lib.dp_conv2d_kernel_class(C.byref(p)) == 7) == (Ci == 512 and live is None)
+    p.n_dev = None
+    monkeypatch.setenv("DP_CONV_ROWS", "2")
     nl = N if live is None else live
     out = torch.full((N, H, W, Co), 7.0, dtype=e.tdt, device=e.device)      # slots behind the live count must stay untouched
     got = e.conv(layer, xa, relu=relu, out=out, n_dev=n_dev)
