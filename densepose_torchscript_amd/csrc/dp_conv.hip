@@ -1092,7 +1092,6 @@ static int num_cus() {
 
 static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   const int es = p->dtype == DP_F32 ? 4 : 2;
-  if (p->Cout <= 64) return DP_CONV_K64;
   // ring kernels: a 64-byte plane inside one tap, <= 32 taps (per-row tap validity is a bit mask), tensors addressable
   // through 32-bit buffer offsets
   const bool ring_ok = (p->Cin * es) % 64 == 0 && p->ntaps >= 1 && p->ntaps <= 32 &&
@@ -1106,13 +1105,20 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   const bool up_res = p->residual && p->rshift == 1 && p->Ho % 2 == 0 && p->Wo % 2 == 0 && p->rsH == (long long)(p->Wo / 2) * p->rsW &&
                       p->rsN == (long long)(p->Ho / 2) * p->rsH && (long long)(p->N + 2) * p->rsN * 2 < (1ll << 31);
   // slice shapes: 256 couts with K = 2 / 4 / 8 planes of 64 B, or exactly 128 couts with K = 16 planes (the 512 -> 128 conv1 of res3)
+  // ... or exactly 64 couts with K = 2 planes (res2.0 conv1 on the pooled stem output, resnet.py:192-193: 138 MB in / out at batch 8,
+  // 40 us at 110 TFLOP/s on the generic kernel in round 3)
   const bool stream_shape = ((kb == 128 || kb == 256 || kb == 512) && p->Cout % 256 == 0 && p->Cout_w % 256 == 0) ||
-                            (kb == 1024 && p->Cout == 128 && p->Cout_w == 128);
-  const bool stream_ok = es == 2 && p->ntaps == 1 && p->stride == 1 && (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == 0 && p->wi_off == 0 && p->H == p->Ho && p->W == p->Wo &&
+                            (kb == 1024 && p->Cout == 128 && p->Cout_w == 128) || (kb == 128 && p->Cout == 64 && p->Cout_w == 128);
+  const bool stream_ok = es == 2 && !p->n_dev && p->ntaps == 1 && p->stride == 1 && (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == 0 && p->wi_off == 0 && p->H == p->Ho && p->W == p->Wo &&
                          stream_shape && p->Kpad == p->Cin &&
                          !p->out_f32 && lin_out && (lin_res || up_res) && M >= 4096 &&
                          // 32-bit buffer offsets, rows up to one grid stride of tiles past the end are addressed
                          (M + (1ll << 16)) * 2 * (p->Cin > p->osW ? p->Cin : (p->osW > p->rsW ? p->osW : p->rsW)) < (1ll << 31);
+  if (p->Cout <= 64) {
+    const char* se64 = getenv("DP_CONV_STREAM");
+    if (stream_ok && !p->in2 && !getenv("DP_CONV_BIG") && !(se64 && atoi(se64) == 0)) return DP_CONV_STREAM;
+    return DP_CONV_K64;
+  }
   if (p->in2) {   // second source (K-concatenated pointwise layer): the LDS-ring kernels implement it (DP_CONV_BIG=2: the 128x128 one)
     const char* f2 = getenv("DP_CONV_BIG");
     if (!ring_ok) return -1;
@@ -1201,6 +1207,18 @@ static int choose_ring256_tp(const dp_conv_params* p, long long M) {
   return best;
 }
 
+// dp_conv_params.split_k is honoured when the split instances of the LDS-ring kernels take the layer; otherwise the layer runs unsplit
+// on whatever kernel it would get without the field (round 3 returned DP_ERR_UNSUPPORTED here: a batch whose fc1 input passes 2 GiB,
+// 86 frames, turned from "generic kernel" into a hard error)
+static bool split_legal(const dp_conv_params* p) {
+  const int es = p->dtype == DP_F32 ? 4 : 2;
+  const bool ring_ok = (p->Cin * es) % 64 == 0 && p->ntaps >= 1 && p->ntaps <= 32 &&
+                       (long long)p->N * p->H * p->W * p->Cin * es < (1ll << 31) && (long long)p->Cout_w * p->Kpad * es < (1ll << 31);
+  const bool lin_out = p->osH == (long long)p->Wo * p->osW && p->osN == (long long)p->Ho * p->osH;
+  return p->split_k > 1 && es == 2 && ring_ok && p->split_ws && !p->residual && !p->head_out && !p->in2 && !p->post_res && !p->out_f32 &&
+         !p->n_dev && lin_out && p->out && p->Cout % 128 == 0 && p->Kpad * es / 64 >= 2 * p->split_k;
+}
+
 static bool split_uses_256(const dp_conv_params* p, long long M) {
   const int es = p->dtype == DP_F32 ? 4 : 2;
   const int planes = p->Kpad * es / 64;
@@ -1212,14 +1230,14 @@ static bool split_uses_256(const dp_conv_params* p, long long M) {
 extern "C" int dp_conv2d_kernel_class(const dp_conv_params* p) {
   if (!p) return -1;
   const long long M = (long long)p->N * p->Ho * p->Wo;
-  if (p->split_k > 1) return split_uses_256(p, M) ? DP_CONV_RING256 : DP_CONV_RING128;
+  if (split_legal(p)) return split_uses_256(p, M) ? DP_CONV_RING256 : DP_CONV_RING128;
   return choose_conv_kernel(p, M);
 }
 
 extern "C" int dp_conv2d_tile_rows(const dp_conv_params* p) {
   if (!p) return -1;
   const long long M = (long long)p->N * p->Ho * p->Wo;
-  if (p->split_k > 1) return split_uses_256(p, M) ? 256 : 128;
+  if (split_legal(p)) return split_uses_256(p, M) ? 256 : 128;
   switch (choose_conv_kernel(p, M)) {
     case DP_CONV_RING256: return 32 * choose_ring256_tp(p, M);
     case DP_CONV_RING256x128: return 256;
@@ -1280,17 +1298,11 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   a.out_linear = (p->osH == (long long)p->Wo * p->osW && p->osN == (long long)p->Ho * p->osH) ? 1 : 0;
   a.res_linear = (p->residual && p->rshift == 0 && p->rsH == (long long)p->Wo * p->rsW && p->rsN == (long long)p->Ho * p->rsH) ? 1 : 0;
   hipStream_t s = as_stream(stream);
-  if (p->split_k > 1) {
-    // Split-K (long-K layers with few pixel tiles: the box head's fc1, res5's 3x3): the K planes are cut into split_k segments,
-    // each (tile, segment) workgroup writes fp32 partial sums, one pass adds them in segment order (+ bias, activation). The
+  if (split_legal(p)) {
+    // Split-K (long-K layers with few pixel tiles: the box head's fc1, res5's 1x1 conv1, fpn_lateral5): the K planes are cut into split_k
+    // segments, each (tile, segment) workgroup writes fp32 partial sums, one pass adds them in segment order (+ bias, activation). The
     // segment count belongs to the LAYER - the caller passes the same value whatever the batch - so a pixel's summation order is
     // fixed; what depends on the launch is only the tile shape: 256 x 256 once that gives about a chip of workgroups, else 128 x 128.
-    const bool ring_ok = (p->Cin * es) % 64 == 0 && p->ntaps >= 1 && p->ntaps <= 32 &&
-                         (long long)p->N * p->H * p->W * p->Cin * es < (1ll << 31) && (long long)p->Cout_w * p->Kpad * es < (1ll << 31);
-    if (!(es == 2 && ring_ok && p->split_ws && !p->residual && !p->head_out && !p->in2 && !p->post_res && !p->out_f32 && !p->n_dev && a.out_linear &&
-          p->out && p->Cout % 128 == 0))
-      return dp_fail(DP_ERR_UNSUPPORTED, "dp_conv2d_nhwc: split_k needs a 16-bit layer the LDS-ring kernels take, a plain NHWC output, a workspace, and "
-                                          "no residual / head / second source / post_res / n_dev");
     const int planes = p->Kpad * es / 64;
     const int per = (planes + p->split_k - 1) / p->split_k;
     const int n_seg = (planes + per - 1) / per;      // every segment non-empty
@@ -1325,6 +1337,7 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
     a.n_tiles = 0;
     const int kp = p->Cin * es / 64;
     if (kp == 16) { DP_BY_DTYPE((launch_conv_stream<T, 16, 2>(a, s))); }
+    if (p->Cout == 64) { DP_BY_DTYPE((launch_conv_stream<T, 2, 1>(a, s))); }
     if (kp == 2) { DP_BY_DTYPE((launch_conv_stream<T, 2>(a, s))); }
     if (kp == 4) { DP_BY_DTYPE((launch_conv_stream<T, 4>(a, s))); }
     DP_BY_DTYPE((launch_conv_stream<T, 8>(a, s)));

@@ -524,7 +524,7 @@ bool dp_conv_wsr_ok(const dp_conv_params* p) {
   const long long M = (long long)p->N * p->H * p->W;
   const bool shape = (p->Cin == 128 && p->Cout == 128 && p->Cout_w == 128) || (p->Cin == 256 && p->Cout == 256 && p->Cout_w == 256);
   const int rp = p->Cin == 128 ? kWsrRP128 : kWsrRP256;
-  return (p->dtype == DP_BF16 || p->dtype == DP_F16) && shape && p->ntaps == 9 && p->Kpad == 9 * p->Cin && p->stride == 1 &&
+  return (p->dtype == DP_BF16 || p->dtype == DP_F16) && !p->n_dev && shape && p->ntaps == 9 && p->Kpad == 9 * p->Cin && p->stride == 1 &&
          (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == -1 && p->wi_off == -1 && p->H == p->Ho && p->W == p->Wo &&
          !p->residual && !p->out_f32 && !p->head_out && p->out && p->osW == p->Cout && p->osH == (long long)p->W * p->Cout &&
          p->osN == (long long)p->H * p->W * p->Cout && p->H >= 2 * rp && M >= 2048 && M * 2 * p->Cin < (1ll << 31) &&

@@ -213,6 +213,9 @@ class PackedModel:
             L[p + "conv3"] = bnconv(p + "conv3", A8(cmid), 1, 0)
             # (res5's 3x3 - 25 x 42 pixels per frame against K = 4608 - ran split-K in three segments in round 3; in the 16-bit modes it
             # now runs on the row-streaming weight-stationary kernel, dp_conv_rows.hip, whatever the batch)
+            # (res5's conv1 - 132 tiles of 128 x 256 at batch 8, each walking K = 2048 - was tried with two split-K segments in round 4:
+            # 40 -> 50 us, the 128 x 128 split instance plus the reduction pass cost more than the idle half of the chip; fpn_lateral5
+            # with four: 34 -> 37 us. Not set.)
             # first block of res3 / res4 / res5 in the 16-bit modes: the projection shortcut as extra K planes of conv3 (one launch,
             # the shortcut tensor is never written or read back; fp32 parity mode keeps the reference's two convolutions + add)
             if sc and stage != "res2" and dtype != DP_F32 and A8(cmid) % 32 == 0 and A8(cin) % 32 == 0 and (A8(cmid) + A8(cin)) % 64 == 0:

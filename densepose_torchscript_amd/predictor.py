@@ -50,6 +50,9 @@ class _HostFrameRing:
     def upload(self, frames, consumer_stream):
         """frames: list of equal-shape CPU uint8 tensors (any strides). -> (device tensor [n, *shape], slot); the caller records
         slot["consumed"] on the stream that read the device tensor once its kernel is launched."""
+        for f in frames:      # the landing buffers are uint8 and a contiguous frame is copied byte-wise: anything else would arrive truncated
+            if f.dtype != torch.uint8:
+                raise TypeError("host frames must be uint8 tensors (defaults.py:76-80), got %s" % f.dtype)
         key = (len(frames), tuple(frames[0].shape))
         ring = self.rings.get(key)
         if ring is None:

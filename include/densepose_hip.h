@@ -119,7 +119,8 @@ typedef struct {
    * skipped (N keeps sizing the launch and the tensors). The DensePose head runs on R detected boxes (roi_head.py:126-158); R is
    * known on the device only - sizing its launches on the host costs a device -> host round trip in the middle of every step.
    * Rows behind *n_dev inside the last live tile are computed on whatever the input holds: every image (ROI) is independent,
-   * their outputs are never read. */
+   * their outputs are never read. Honoured by the tiled kernels (classes 0 - 4) and class 7; a launch with n_dev is never given to
+   * the persistent kernels that ignore it (classes 5 and 6: they would do the full work on all N images). */
   const int32_t* n_dev;
   /* Second source of a pointwise (1 tap, stride 1) layer: K = Cin channels of `in` followed by Cin2 channels of `in2`, an
    * [N, H2, W2, Cin2] tensor read at pixel (ho * stride2, wo * stride2); Kpad = Cin + Cin2, both multiples of 64 bytes; the
@@ -133,8 +134,9 @@ typedef struct {
    * index order, then bias and activation. For layers with a long K and few pixel tiles (the box head's fc1: K = 12544 over 1000
    * rows per image, box_head.py:60-67; res5's 3x3): one workgroup per tile streams megabytes of weights while most CUs idle. The
    * value is a property of the LAYER: pass the same split_k whatever the batch, and a row's summation order - hence its bits -
-   * does not depend on what else is in the batch. 16-bit storage, LDS-ring kernels, plain NHWC output, no residual / head /
-   * second source / post_res / n_dev (DP_ERR_UNSUPPORTED otherwise). 0 or 1 = off. */
+   * does not depend on what else is in the batch. Honoured for 16-bit storage, layers the LDS-ring kernels take (64-byte K planes inside
+   * one tap, tensors below 2 GiB), plain NHWC output, at least two planes per segment, no residual / head / second source / post_res /
+   * n_dev; anything else runs UNSPLIT on the kernel it would get without the field (no error). 0 or 1 = off. */
   int32_t split_k;
   void* split_ws;
 } dp_conv_params;
