@@ -614,6 +614,8 @@ class Engine:
                                           2 if lvl == "p2" else 1) for lvl, nconv in layout)
                 and all(feats[lvl].H * (1 << (nconv - 1)) * 2 == feats["p2"].H and feats[lvl].W * (1 << (nconv - 1)) * 2 == feats["p2"].W
                         for lvl, nconv in layout if lvl != "p2"))
+        if self.keep_intermediates:
+            self.inter["decoder_fold"] = bool(fold)      # the per-layer choice a storage-emulating oracle has to mirror (tests)
         if fold:
             low_sum = None
             for lvl, nconv in layout:
@@ -887,6 +889,8 @@ class Engine:
         # the returned `scores` are slices of this tensor: with graph replay st[...] lives in the graph's memory pool and is
         # overwritten by the next replay, so the results get their own copy (n x D floats)
         det_scores = det_scores.clone()
+        if self.keep_intermediates:
+            self.inter["detections"] = (det_boxes, det_scores, det_counts)    # network-input coordinates, before detector_postprocess
         flops0 = self.flops_last
         coarse, fine, u, v = self.densepose_branch(st["feats"], det_boxes, det_counts, st.get("dec"))
         flops_dp = self.flops_last - flops0

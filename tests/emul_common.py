@@ -1,0 +1,157 @@
+"""Shared by tests/test_gpu_e2e.py and tools/emul_stats.py: run the HIP engine in a 16-bit mode and the storage-emulating CPU oracle
+(oracle/ref_storage.py) on the same golden case, the oracle's DensePose branch on the ENGINE's detections (so that a borderline
+detection that comes or goes is out of the comparison), and compare stage by stage."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from conftest import golden_case_inputs, load_golden
+
+IUV_KEYS = ("pred_densepose_coarse_segm", "pred_densepose_fine_segm", "pred_densepose_u", "pred_densepose_v")
+ULP = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}      # half a unit in the last place of a value in [1, 2)
+
+
+def _nchw(act):
+    return act.t.float().cpu().permute(0, 3, 1, 2)
+
+
+def run_pair(name, dtype):
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    from densepose_torchscript_amd.weights import resnet_blocks
+    from oracle.ref_storage import StorageOracle
+    meta, z = load_golden(name)
+    cfg, state, img = golden_case_inputs(meta)
+    pred = DensePosePredictor(cfg, state, dtype=dtype, resize="host", check_keep=True)
+    eng = pred.engine
+    eng.keep_intermediates = True
+    out = pred(torch.from_numpy(img))
+    torch.cuda.synchronize()
+    out = {k: v.cpu() for k, v in out.items()}
+    inter = eng.inter
+    fused = [p for p in ("backbone.bottom_up.%s.%d." % (st, b) for st, b, *_ in resnet_blocks(cfg))
+             if eng.fuse_shortcut and (p + "conv3+shortcut") in eng.model.layers]
+    fold = bool(inter.get("decoder_fold", False))
+    em = StorageOracle(cfg, state, dtype, fused_shortcuts=fused, decoder_fold=fold)
+    image, height, width = em.resize(torch.from_numpy(img))
+    images, padding = em.preprocess(image)
+    feats = em.backbone(images)
+    stages = {k: (_nchw(inter[k])[:, : feats[k].shape[1]], feats[k]) for k in ("p2", "p3", "p4", "p5", "p6")}
+    det_boxes, det_scores, det_counts = inter["detections"]
+    R = int(det_counts[0])
+    boxes = det_boxes[0, :R].float().cpu()
+    dp, extra = em.densepose_branch(feats, boxes, want_all=True)
+    if cfg.dp_decoder_on:
+        stages["decoder_out"] = (_nchw(inter["decoder_out"])[:, : extra["decoder_out"].shape[1]], extra["decoder_out"])
+    if R:
+        stages["dp_head_out"] = (_nchw(inter["dp_head_out"])[:R, : extra["dp_head_out"].shape[1]], extra["dp_head_out"])
+        for k, t in zip(IUV_KEYS, dp):
+            stages[k] = (out[k], t)
+    return dict(meta=meta, z=z, cfg=cfg, out=out, em_iuv=dict(zip(IUV_KEYS, dp)), stages=stages, R=R, fold=fold, fused=fused)
+
+
+def stage_stats(got, ref, dtype):
+    """-> dict: largest deviation relative to the tensor's largest value, and the share of elements further than 1 / 2 / 8 units in the
+    last place of the STORAGE type (of the reference element's magnitude; floor: 2^-6 of the tensor's largest value)"""
+    got, ref = got.double(), ref.double()
+    top = float(ref.abs().max()) or 1.0
+    d = (got - ref).abs()
+    unit = 2.0 * ULP[dtype] * torch.clamp(ref.abs(), min=top * 2.0 ** -6)
+    return {"max_rel_to_top": float(d.max()) / top, "gt1ulp": float((d > unit).double().mean()), "gt2ulp": float((d > 2 * unit).double().mean()),
+            "gt8ulp": float((d > 8 * unit).double().mean()), "n": int(d.numel())}
+
+
+def _labels_and_margins(iuv, box):
+    """visualizer.py:10-17 on one detection: (labels [h, w], margin [h, w] = how far the decision is from flipping: the smaller of the
+    top-two gaps of the resampled coarse and fine maps)"""
+    x, y, w, h = [int(t) for t in box.long().tolist()]
+    w, h = max(w, 1), max(h, 1)
+    cb = F.interpolate(iuv["pred_densepose_coarse_segm"], (h, w), mode="bilinear", align_corners=False)[0]
+    fb = F.interpolate(iuv["pred_densepose_fine_segm"], (h, w), mode="bilinear", align_corners=False)[0]
+    labels = fb.argmax(dim=0) * (cb.argmax(dim=0) > 0).long()
+    tc = cb.topk(2, dim=0).values
+    tf = fb.topk(2, dim=0).values
+    return labels, torch.minimum(tc[0] - tc[1], tf[0] - tf[1])
+
+
+def label_stats(r):
+    """part labels of the engine's maps against the oracle's, both on the engine's boxes -> (pixels, differing pixels, the largest
+    decision margin (in the oracle's maps) among the differing pixels)"""
+    out, em = r["out"], r["em_iuv"]
+    tot = diff = 0
+    worst = 0.0
+    wh = out["pred_boxes"].clone()
+    wh[:, 2] -= wh[:, 0]
+    wh[:, 3] -= wh[:, 1]
+    for i in range(r["R"]):
+        le, _ = _labels_and_margins({k: out[k][i:i + 1] for k in IUV_KEYS}, wh[i])
+        lo, mo = _labels_and_margins({k: em[k][i:i + 1] for k in IUV_KEYS}, wh[i])
+        ne = le != lo
+        tot += int(ne.numel())
+        diff += int(ne.sum())
+        if bool(ne.any()):
+            worst = max(worst, float(mo[ne].max()))
+    return tot, diff, worst
+
+
+def run_forced(name, dtype):
+    """Every dp_conv2d_nhwc launch (and GroupNorm) of the engine recorded, then the storage-emulating oracle run with teacher forcing
+    (oracle/ref_storage.py) on the engine's detections: -> ({layer name: stats of oracle(engine's input) against the engine's output},
+    stage_stats of the four IUV maps, label_stats)."""
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    from densepose_torchscript_amd.weights import resnet_blocks
+    from oracle.ref_storage import StorageOracle
+    meta, z = load_golden(name)
+    cfg, state, img = golden_case_inputs(meta)
+    pred = DensePosePredictor(cfg, state, dtype=dtype, resize="host", check_keep=True)
+    eng = pred.engine
+    # launches that fuse several layers are bit-identical to the layer-by-layer path (tests/test_gpu_kernels.py) and have no per-layer
+    # outputs to record
+    eng.fuse_stem_pool = eng.fuse_bottleneck = eng.fuse_rpn_head = False
+    eng.keep_intermediates = True
+    rec = {}
+    conv0, gn0 = eng.conv, eng.groupnorm
+
+    def conv(layer, x, *a, **kw):
+        out = conv0(layer, x, *a, **kw)
+        if x.H > 1 and kw.get("out_geom") is None and not kw.get("out_f32"):      # (not the fully connected layers / sub-pixel deconvs)
+            c0 = kw.get("out_c_off", 0)
+            rec.setdefault(layer.name, []).append(out.t.float().cpu().permute(0, 3, 1, 2)[:, c0: c0 + layer.cout])
+        return out
+
+    def groupnorm(x_t, R, HW, Cc, c_stride, c_off, gn, **kw):
+        gn0(x_t, R, HW, Cc, c_stride, c_off, gn, **kw)
+        key = next(k for k, v in eng.model.gn.items() if v is gn)
+        side = int(round(HW ** 0.5))
+        rec.setdefault("gn:" + key, []).append(x_t.float().cpu().reshape(R, HW, c_stride)[:, :, c_off: c_off + Cc].permute(0, 2, 1).reshape(R, Cc, side, side))
+    eng.conv, eng.groupnorm = conv, groupnorm
+    out = {k: v.cpu() for k, v in pred(torch.from_numpy(img)).items()}
+    torch.cuda.synchronize()
+    fused = [p for p in ("backbone.bottom_up.%s.%d." % (st, b) for st, b, *_ in resnet_blocks(cfg))
+             if eng.fuse_shortcut and (p + "conv3+shortcut") in eng.model.layers]
+    em = StorageOracle(cfg, state, dtype, fused_shortcuts=fused, decoder_fold=bool(eng.inter.get("decoder_fold", False)))
+    det_boxes, det_scores, det_counts = eng.inter["detections"]
+    R = int(det_counts[0])
+    # engine layer names -> the oracle's: the RPN's 1x1 heads are one 16-channel layer in the engine, two in the reference (not forced:
+    # their fp32 outputs feed no layer); the DeepLab head's GroupNorms are keyed by their weight names
+    hd = "roi_heads.densepose_head."
+    gn_names = {"gn:dp_fcn%d" % (i + 1): "gn:" + hd + "body_conv_fcn%d.norm.weight" % (i + 1) for i in range(cfg.dp_num_convs)}
+    gn_names.update({"gn:aspp%d" % i: "gn:" + hd + "ASPP.convs.%d.%d.weight" % (i, 2 if i == 4 else 1) for i in range(5)})
+    force = {}
+    for k, v in rec.items():
+        if k == "rpn_head":
+            continue
+        if k.startswith("gn:") or k.startswith(hd):
+            v = [t[:R] for t in v]
+        force[gn_names.get(k, k)] = v
+    em.force = force
+    image, height, width = em.resize(torch.from_numpy(img))
+    images, padding = em.preprocess(image)
+    feats = em.backbone(images)
+    em.rpn_head([feats[k] for k in ("p2", "p3", "p4", "p5", "p6")])
+    iuv_stats, lab = {}, (0, 0, 0.0)
+    if R:
+        dp, _ = em.densepose_branch(feats, det_boxes[0, :R].float().cpu())
+        r = dict(out=out, em_iuv=dict(zip(IUV_KEYS, dp)), R=R)
+        iuv_stats = {k: stage_stats(out[k], t, dtype) for k, t in zip(IUV_KEYS, dp)}
+        lab = label_stats(r)
+    return em.forced_stats, iuv_stats, lab

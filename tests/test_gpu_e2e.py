@@ -185,11 +185,12 @@ def test_device_resize_equals_host_resize():
 # part-label agreement with the fp32 golden on the matched detections, measured with tools/measure_bands.py (round 3): bf16 0.996 /
 # 0.965 / 0.985 (tiny_r50_s1x_a / full_r50_s1x_small / the 800x1333 headline frame), fp16 1.0 / 0.9988 / 0.9987; the DeepLab cases
 # have tiny boxes (3 - 384 label pixels in all: one flipped pixel is 0.3 - 33 %), bf16 0.67 - 0.95, fp16 0.948 - 0.996
-BF16_LABEL_FLOOR = {"tiny_r50_s1x_a": 0.97, "full_r50_s1x_small": 0.93, "full_r50_dl_p28": 0.5}
-# largest IUV deviation on the matched detections, relative to the largest reference value of the same map (round 3, tools/measure_bands.py):
-# 0.016 / 0.027 on the s1x cases - held to 3x that; the DeepLab head at pool 28 (GroupNorm over 8 / 16-channel groups of random-weight
-# activations, logits of range +-2) measures 0.25 - 0.44 depending on the build's rounding points: a regression guard only
-BF16_IUV_BAND = {"tiny_r50_s1x_a": 0.05, "full_r50_s1x_small": 0.08, "full_r50_dl_p28": 0.6}
+BF16_LABEL_FLOOR = {"tiny_r50_s1x_a": 0.97, "full_r50_s1x_small": 0.93, "full_r50_s1x_800x1333": 0.93}
+# largest IUV deviation on the matched detections, relative to the largest reference value of the same map (tools/measure_bands.py):
+# 0.016 / 0.027 on the s1x cases - held to 3x that. (The DeepLab pool-28 case left this band test in round 4: it is gated against the
+# storage-emulating oracle instead - test_16bit_layers_equal_the_storage_oracle_teacher_forced / test_16bit_end_to_end_... above.)
+# (the headline frame: 7 of 8 detections within 1.5 px; one of the matched ones sits 1 px off and its maps deviate by 0.18 of their range)
+BF16_IUV_BAND = {"tiny_r50_s1x_a": 0.05, "full_r50_s1x_small": 0.08, "full_r50_s1x_800x1333": 0.3}
 FP16_LABEL_FLOOR = 0.9
 
 
@@ -238,16 +239,78 @@ def _label_agreement(out, z, box_tol):
     return eq / max(tot, 1), tot
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# The 16-bit modes against the STORAGE-EMULATING oracle (oracle/ref_storage.py): the CPU restatement with every tensor rounded to
+# the storage type where the engine stores it. tools/emul_layers.py / tools/emul_stats.py print what the bounds below were read from.
+TOP_ULP = {"bf16": 2.0 ** -7, "fp16": 2.0 ** -10}     # one unit in the last place of a tensor's largest value, relative to it
+FORCED_CASES = [("full_r50_s1x_small", "bf16"), ("full_r50_s1x_small", "fp16"), ("full_r50_s1x_800x1333", "bf16"), ("full_r101_s1x_small", "bf16"),
+                ("full_r50_dl_p28", "bf16"), ("tiny_r101_dl_p28_video", "fp16"), ("tiny_r101_dl_p28_video", "bf16"), ("tiny_r50_legacy", "bf16")]
+
+
+@pytest.mark.parametrize("name,dt", FORCED_CASES)
+def test_16bit_layers_equal_the_storage_oracle_teacher_forced(name, dt):
+    """PARITY of the throughput dtypes, layer by layer: every convolution (and GroupNorm) output of the engine against the oracle's
+    computation of that layer FROM THE ENGINE'S OWN INPUT TENSOR (teacher forcing). The two then differ by the order of the fp32
+    accumulation alone: a handful of elements per ten thousand land on the other side of a rounding boundary - by one unit in the
+    last place, or by less than that of the tensor's largest value where cancellation left a small result. Measured (round 4,
+    tools/emul_layers.py): 0.0001 - 0.2 % of a layer's elements, <= 0.7 ulp of the top value for convolutions; GroupNorm <= 0.03 % and
+    <= 0.4 ulp at the real DeepLab geometry (full_r50_dl_p28 = BASELINE.json configs[3]: the bf16 GroupNorm / dilated-tap kernels are
+    right; the low label agreement of that mode with the fp32 golden is rounding noise through eight normalisations of random-weight
+    maps), up to 36 % one-ulp flips in the tiny-width fixtures whose groups hold ONE channel. The fp32 IUV maps computed from the
+    forced head output agree to 1e-6 and the part labels are identical."""
+    from emul_common import run_forced
+    stats, iuv, (npx, ndiff, margin) = run_forced(name, dt)
+    assert len(stats) >= 30
+    tiny = name.startswith("tiny")
+    for layer, st in stats.items():
+        frac = st["differ"] / st["n"]
+        if layer.startswith("gn:"):
+            assert st["max_rel_to_top"] <= (4.0 if not tiny else 8.0) * TOP_ULP[dt], (layer, st)
+            assert tiny or frac <= 2e-3, (layer, st)
+        else:
+            assert st["max_rel_to_top"] <= 1.5 * TOP_ULP[dt], (layer, st)
+            assert frac <= (5e-3 if not tiny else 4e-2), (layer, st)
+    for k, st in iuv.items():
+        assert st["max_rel_to_top"] <= 1e-5, (k, st)
+    assert ndiff <= 2 and margin <= 1e-4, (npx, ndiff, margin)
+
+
+E2E_EMUL_CASES = [("full_r50_s1x_800x1333", "bf16"), ("full_r50_s1x_800x1333", "fp16"), ("full_r101_s1x_small", "bf16"), ("full_r50_dl_p28", "bf16"),
+                  ("tiny_r50_s1x_a", "bf16"), ("tiny_r50_legacy", "bf16")]
+
+
+@pytest.mark.parametrize("name,dt", E2E_EMUL_CASES)
+def test_16bit_end_to_end_against_the_storage_oracle(name, dt):
+    """The same comparison WITHOUT forcing: engine and oracle each run their own 60 layers (the oracle's DensePose branch on the
+    engine's detections, so that a borderline detection is out of the picture). A one-ulp flip in one layer moves hundreds of sums of
+    the next by a fraction of their own ulp, so the two runs decorrelate at the one-ulp level within a few layers; what stays bounded
+    is the deviation relative to a tensor's scale. Measured (tools/emul_stats.py): FPN maps / decoder / head output <= 1.7 ulp of the
+    top value (bf16 0.0055 - 0.0135, fp16 0.0008 - 0.0017), IUV maps <= 3.4 (bf16 0.027, fp16 0.0019); part labels differ on 0.1 - 1.8 %
+    of the box pixels, every one of them a pixel whose decision margin is inside the IUV deviation. Held to ~1.5x - 2x that."""
+    from emul_common import label_stats, run_pair, stage_stats
+    r = run_pair(name, dt)
+    assert r["R"] > 0
+    for k, (got, ref) in r["stages"].items():
+        st = stage_stats(got, ref, dt)
+        bound = (6.0 if k.startswith("pred_") else 3.0) * TOP_ULP[dt]
+        assert st["max_rel_to_top"] <= bound, (k, st)
+    npx, ndiff, margin = label_stats(r)
+    iuv_dev = max(stage_stats(*r["stages"][k], dt)["max_rel_to_top"] * float(r["stages"][k][1].abs().max()) for k in IUV_KEYS[:2])
+    assert npx > 0 and ndiff <= 0.03 * npx, (npx, ndiff)
+    # a pixel may only differ where the oracle's own decision is closer than (twice) the largest logit deviation of this run
+    assert margin <= 2.0 * iuv_dev + 1e-6, (npx, ndiff, margin, iuv_dev)
+
+
 # bf16 has 8 significant bits and these are RANDOM-weight networks (no trained smoothness): through ~60 layers the IUV logits of
 # a matched detection move by 1 - 20 % of their range (tools/measure_bands.py prints the per-detection numbers; bench.py reports
 # the same quantities for the headline workload: 1 - 4 % there), and a borderline detection may be replaced by another one.
 # The bands below are those measurements with ~2x headroom - a regression guard for the throughput mode, not a parity claim.
-@pytest.mark.parametrize("name", ["tiny_r50_s1x_a", "full_r50_s1x_small", "full_r50_dl_p28"])
+@pytest.mark.parametrize("name", ["tiny_r50_s1x_a", "full_r50_s1x_small", "full_r50_s1x_800x1333"])
 def test_bf16_mode_stays_in_its_measured_band(name):
     """Throughput mode (bf16 operands, fp32 accumulate) against the fp32 reference golden: the detections are found (box within
     1.5 px, score within 0.05; at most one borderline detection may come or go) and the IUV maps of the matched detections
-    stay within the per-case band BF16_IUV_BAND of the map's range. BASELINE.json configs[3] (R_50_FPN_DL bf16) = the full_r50_dl_p28 case:
-    bf16 GroupNorm / global average pool / broadcast at the real pool-28 geometry."""
+    stay within the per-case band BF16_IUV_BAND of the map's range - the headline frame (BASELINE.json configs[1], 800 x 1333, R = 8)
+    included: every fusion that moves a rounding point moves THIS number, and bench.py only prints it."""
     meta, z, cfg, pred, out = _run(name, "bf16")
     for k in IUV_KEYS:
         assert torch.isfinite(out[k]).all()
