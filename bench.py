@@ -151,6 +151,18 @@ def r_sensitivity(args, state, frames, device):
     return out
 
 
+def multi_gpu_record(values, world, device):
+    """`multi_gpu` of the JSON line: what every rank measured for itself, as MIN / MAX / per-rank lists (the driver computes scaling
+    efficiency from `value`; this says WHERE a shortfall comes from - the host feed path or the GPUs)."""
+    from densepose_torchscript_amd.parallel import rank_stats
+    import torch.distributed as dist
+    stats = rank_stats(values, device)
+    return {"ranks_in_process_group": dist.get_world_size() if dist.is_initialized() else 1, "world": world,
+            "backend": dist.get_backend() if dist.is_initialized() else None, **stats,
+            "note": "sustained / host_frames: every rank runs the loop at the same time (frames resident in HBM / starting in pageable host "
+                    "memory on every rank at once); weight_broadcast: the one RCCL broadcast of the packed weights from rank 0"}
+
+
 def spawn_selftest():
     """`--spawn-selftest`: what a rank does up to the first collective, without a GPU (gloo) - exercised by the CPU tests
     to cover the self-launch path of `bench.py --gpus N`."""
@@ -161,8 +173,11 @@ def spawn_selftest():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
+    # the multi-rank part of the benchmark record, with stand-in numbers: same keys, same collective (parallel.rank_stats)
+    multi = multi_gpu_record({"sustained_images_per_s": 100.0 + rank, "host_frames_images_per_s": 90.0 - rank,
+                              "weight_broadcast_s": 0.01 * (rank + 1), "weight_broadcast_bytes": 1.0e6}, world, None)
     if rank == 0:
-        print(json.dumps({"selftest": "spawn", "world": world, "max_over_ranks": float(t.item())}), flush=True)
+        print(json.dumps({"selftest": "spawn", "world": world, "max_over_ranks": float(t.item()), "multi_gpu": multi}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -222,8 +237,16 @@ def main():
             if k.endswith("running_var"):
                 state[k] += 1.0
     pred = DensePosePredictor(cfg, state, dtype=args.dtype, device=device, resize="device", num_streams=args.streams, use_graphs=not args.no_graphs)
+    bcast_s, bcast_bytes = 0.0, 0
     if world > 1:
-        parallel.broadcast_tensors(pred.engine.model.parameter_tensors(), src=0)
+        tensors = pred.engine.model.parameter_tensors()
+        bcast_bytes = sum(t.numel() * t.element_size() for t in tensors)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        parallel.broadcast_tensors(tensors, src=0)
+        torch.cuda.synchronize()
+        bcast_s = time.perf_counter() - t0
     eng = pred.engine
     # `--streams 1 --no-graphs` is the fully serialized configuration (one kernel at a time on the chip) that profiles/ and
     # the roofline pass use; otherwise the decoder also runs beside the RPN / box branch on a side stream
@@ -260,7 +283,7 @@ def main():
     # clock the chip sustains) and, beside it, the same workload with the frames starting in PAGEABLE HOST memory like the
     # reference's run.py:34-36 hands them over (pinned ring + one H2D per batch on a copy stream, predictor._HostFrameRing)
     sustained = host_rate = None
-    if not args.no_extras and world == 1:
+    if not args.no_extras:
         def timed_loop(fr, seconds):
             for _ in range(2 * pred.pipeline_depth):
                 pred.predict_batch(fr)
@@ -276,12 +299,19 @@ def main():
             pred.join()
             torch.cuda.synchronize()
             return n * len(fr) / (time.perf_counter() - t0), n
+        barrier()                      # N > 1: every rank runs each loop at the same time (per-rank rates: `multi_gpu` below)
         rate, n = timed_loop(frames, 3.0)
         sustained = {"images_per_s": round(rate, 1), "steps": n, "seconds": 3.0}
         host_frames = [f.cpu() for f in frames]
+        barrier()
         rate, n = timed_loop(host_frames, 2.0)
         host_rate = {"images_per_s": round(rate, 1), "steps": n,
                      "note": "frames start in pageable host memory each step (3.2 MB each): gathered into a pinned ring slot, one H2D per batch on a copy stream"}
+    multi = None
+    if world > 1:
+        multi = multi_gpu_record({"sustained_images_per_s": sustained["images_per_s"] if sustained else 0.0,
+                                  "host_frames_images_per_s": host_rate["images_per_s"] if host_rate else 0.0,
+                                  "weight_broadcast_s": bcast_s, "weight_broadcast_bytes": float(bcast_bytes)}, world, device)
     pred.pipeline_depth = 1   # the latency loop and the roofline pass below run batch after batch on one stream
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -413,6 +443,8 @@ def main():
                                       "on a side stream" if overlap else "in line", args.pipeline if pipelined else 1)},
             "roofline": roofline,
         }
+        if multi is not None:
+            result["multi_gpu"] = multi
         if world == 1 and not args.no_extras:
             result["accuracy_vs_fp32_reference"] = accuracy_vs_golden(pred, args.dtype) if (
                 args.config == "densepose_rcnn_R_50_FPN_s1x" and args.dets == 8 and hw == (800, 1333)) else None

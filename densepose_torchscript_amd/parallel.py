@@ -75,6 +75,22 @@ def broadcast_tensors(tensors, src=0, bucket_bytes=256 << 20, transport=None):
             off += b.numel()
 
 
+def rank_stats(values, device=None):
+    """Per-rank numbers (a dict with the SAME keys on every rank) -> {key: {"min", "max", "per_rank": [...]}} on every rank: one
+    all_gather of a small vector. What a multi-GPU record needs beside the MAX-over-ranks step time: a rank that is slow at
+    feeding its GPU (host gather, H2D copy - the scaling risk of this path, run.py:42-57) shows up as the MIN."""
+    keys = sorted(values)
+    vec = torch.tensor([float(values[k]) for k in keys], dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        parts = [torch.empty_like(vec) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, vec)
+    else:
+        parts = [vec]
+    table = torch.stack([p.cpu() for p in parts])          # [world, keys]
+    return {k: {"min": float(table[:, i].min()), "max": float(table[:, i].max()), "per_rank": [float(x) for x in table[:, i]]}
+            for i, k in enumerate(keys)}
+
+
 def gather_results(local_results, dst=0):
     """Optional: collect the per-frame result dicts (variable R) on rank `dst`, in frame order."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -89,6 +89,13 @@ def test_bench_self_launch_spawns_ranks_over_gloo():
     assert len(lines) == 1, p.stdout.decode()          # ONE JSON line, printed by rank 0
     rec = json.loads(lines[0])
     assert rec["world"] == 2 and rec["max_over_ranks"] == 2.0   # MAX over ranks reached rank 0
+    # the multi-rank part of the benchmark record (bench.multi_gpu_record over parallel.rank_stats): schema and MIN / MAX semantics
+    m = rec["multi_gpu"]
+    assert m["ranks_in_process_group"] == 2 and m["world"] == 2 and m["backend"] == "gloo"
+    for key in ("sustained_images_per_s", "host_frames_images_per_s", "weight_broadcast_s", "weight_broadcast_bytes"):
+        assert set(m[key]) == {"min", "max", "per_rank"} and len(m[key]["per_rank"]) == 2
+        assert m[key]["min"] == min(m[key]["per_rank"]) and m[key]["max"] == max(m[key]["per_rank"])
+    assert m["sustained_images_per_s"]["per_rank"] == [100.0, 101.0] and m["host_frames_images_per_s"]["per_rank"] == [90.0, 89.0]
 
 
 def test_bench_self_launch_propagates_rank_failure():
