@@ -582,6 +582,22 @@ __global__ void count_offsets_kernel(const int* __restrict__ counts, int n, int*
   total[0] = s;
 }
 
+// ... with the rows capped at `limit` slots: image i keeps min(counts[i], limit - rows before it) boxes
+__global__ void count_offsets_limited_kernel(const int* __restrict__ counts, int n, int limit, int* __restrict__ counts_out, int* __restrict__ offsets,
+                                             int* __restrict__ total) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int s = 0;
+  for (int i = 0; i < n; ++i) {
+    offsets[i] = s;
+    int c = counts[i];
+    c = c > 0 ? c : 0;
+    if (c > limit - s) c = limit - s;
+    counts_out[i] = c;
+    s += c;
+  }
+  total[0] = s;
+}
+
 }  // namespace
 
 // runs CALL with the storage type bound to T (float | uint16_t = bf16 bits | _Float16)
@@ -671,6 +687,13 @@ extern "C" int dp_count_offsets(const int32_t* counts, int n_img, int32_t* offse
   DP_REQUIRE(counts && offsets && total && n_img > 0, "dp_count_offsets: bad args");
   hipLaunchKernelGGL(count_offsets_kernel, dim3(1), dim3(64), 0, as_stream(stream), counts, n_img, offsets, total);
   return dp_check_launch("count_offsets_kernel");
+}
+
+extern "C" int dp_count_offsets_limited(const int32_t* counts, int n_img, int limit, int32_t* counts_out, int32_t* offsets, int32_t* total,
+                                        dp_stream_t stream) {
+  DP_REQUIRE(counts && counts_out && offsets && total && n_img > 0 && limit >= 0, "dp_count_offsets_limited: bad args");
+  hipLaunchKernelGGL(count_offsets_limited_kernel, dim3(1), dim3(64), 0, as_stream(stream), counts, n_img, limit, counts_out, offsets, total);
+  return dp_check_launch("count_offsets_limited_kernel");
 }
 
 extern "C" int dp_merge_upsample2x_nhwc(const void* base, const void* const* ups, int n_ups, void* out, int N, int H, int W, int C,

@@ -102,6 +102,7 @@ class Engine:
         self._graph_slots, self._graph_captures = set(), {}
         self._meta_cache = {}
         self._pinned = {}
+        self._r_hwm = {}              # (frames, slots per frame) -> high-water mark of the detections of recent batches (_dp_slots)
 
     # ------------------------------------------------------------------ helpers
     def _stage(self, name):
@@ -724,17 +725,25 @@ class Engine:
         L.check(self.lib.dp_iuv_upsample_split(C.byref(p), self._stream()), "dp_iuv_upsample_split")
         return coarse, fine, u, v
 
-    def densepose_branch(self, feats, det_boxes, det_counts_dev, dec=None):
+    def densepose_branch(self, feats, det_boxes, det_counts_dev, dec=None, slots=None):
         """roi_head.py:126-158 for ALL detection slots of the batch, sized on the DEVICE: the launches cover n x D box slots and
         read the live count R = sum(det_counts) from device memory (dp_count_offsets -> dp_conv_params.n_dev / r_dev), so the host
         never waits for R in the middle of a step. Returns tensors with n x D rows (the first R live) + the offsets tensor."""
         cfg = self.cfg
         n = feats["p2"].N
         D = det_boxes.shape[1]
-        Rmax = n * D
+        # Slots: the branch is launched before the host knows R. Round 3 sized everything for n x DETECTIONS_PER_IMAGE slots - with the
+        # default 100 per image that is 3.9 MB of fp32 IUV maps per slot, 3.1 GB per step at batch 8 however few boxes there are, and
+        # one retained result view pins it all. Now: `slots` (the caller's high-water mark of recent steps, see _dp_slots); the
+        # device caps the compact ROI list at that many rows (dp_count_offsets_limited), and the caller - who reads the true
+        # counts after the step anyway - runs the branch again with more slots in the rare step that overflowed.
+        Rmax = n * D if slots is None else max(1, min(int(slots), n * D))
         offsets = self._empty((n,), torch.int32)
         total = self._empty((1,), torch.int32)
-        L.check(self.lib.dp_count_offsets(det_counts_dev.data_ptr(), n, offsets.data_ptr(), total.data_ptr(), self._stream()), "dp_count_offsets")
+        capped = self._empty((n,), torch.int32)
+        L.check(self.lib.dp_count_offsets_limited(det_counts_dev.data_ptr(), n, Rmax, capped.data_ptr(), offsets.data_ptr(), total.data_ptr(),
+                                                  self._stream()), "dp_count_offsets_limited")
+        det_counts_dev = capped
         if cfg.dp_decoder_on:
             if dec is None:
                 with self._stage("decoder"):
@@ -812,6 +821,18 @@ class Engine:
             dec.t.record_stream(cur)
             self._shared_chip = 0
         return dict(n=n, h=h, w=w, feats=feats, det_boxes=det_boxes, det_scores=det_scores, det_counts=det_counts, dec=dec)
+
+    def _dp_slots(self, n, D, seen=None):
+        """Slot count of the DensePose branch for a batch of n frames: a high-water mark of the box counts of recent batches of that
+        size (+ 25 %, rounded up to 16, at least 16 per frame until a count has been seen), never more than n x D. With `seen`:
+        record a batch's true count (the mark decays by 2 % per batch, so one crowded scene does not size the next hour)."""
+        key = (n, D)
+        hwm = self._r_hwm.get(key)
+        if seen is not None:
+            self._r_hwm[key] = float(seen) if hwm is None else max(float(seen), 0.98 * hwm)
+            return None
+        want = 16 * n if hwm is None else int(hwm * 1.25) + n
+        return max(1, min(n * D, (want + 15) // 16 * 16))
 
     def _pinned_counts(self, key, n):
         buf = self._pinned.get(key)
@@ -892,7 +913,8 @@ class Engine:
         if self.keep_intermediates:
             self.inter["detections"] = (det_boxes, det_scores, det_counts)    # network-input coordinates, before detector_postprocess
         flops0 = self.flops_last
-        coarse, fine, u, v = self.densepose_branch(st["feats"], det_boxes, det_counts, st.get("dec"))
+        slots = self._dp_slots(n, det_boxes.shape[1])
+        coarse, fine, u, v = self.densepose_branch(st["feats"], det_boxes, det_counts, st.get("dec"), slots=slots)
         flops_dp = self.flops_last - flops0
         # detector_postprocess (postprocessing.py:43-54); image_size there is [W_pad, H_pad] (Q1) minus the padding
         D = det_boxes.shape[1]
@@ -922,7 +944,11 @@ class Engine:
         offs = np.zeros((n,), dtype=np.int64)
         offs[1:] = np.cumsum(counts_host)[:-1]
         R = int(counts_host.sum())
-        self.flops_last = flops0 + (flops_dp * R) // max(n * D, 1)     # the launches cover n x D slots, R of them do work
+        self._dp_slots(n, D, seen=R)
+        if R > slots:
+            # more boxes than the high-water mark allowed for (first step of a busier scene): once more with room for all of them
+            coarse, fine, u, v = self.densepose_branch(st["feats"], det_boxes, det_counts, st.get("dec"), slots=self._dp_slots(n, D))
+        self.flops_last = flops0 + (flops_dp * R) // max(slots, 1)     # the launches cover `slots` slots, R of them do work
         if self.keep_intermediates:
             for k in ("dp_pooled", "dp_head_out"):
                 a = self.inter[k]

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("DP_HIP_LIB") or os.path.join(_HERE, "libdensepose_hip
 CSRC = os.path.join(_HERE, "csrc")
 
 DP_F32, DP_BF16, DP_F16 = 0, 1, 2
-ABI_VERSION = 4   # == DP_ABI_VERSION of include/densepose_hip.h (bumped whenever a params struct or the symbol set changes)
+ABI_VERSION = 5   # == DP_ABI_VERSION of include/densepose_hip.h (bumped whenever a params struct or the symbol set changes)
 
 # user-facing dtype names -> (enum, element size)
 DTYPES = {"fp32": DP_F32, "float32": DP_F32, "bf16": DP_BF16, "bfloat16": DP_BF16, "fp16": DP_F16, "float16": DP_F16, "half": DP_F16}
@@ -156,6 +156,7 @@ SYMBOLS = {
     "dp_global_avgpool_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dp_broadcast_hw_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dp_count_offsets": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "dp_count_offsets_limited": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dp_fold_frozen_bn": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
     "dp_conv_taps": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dp_pack_conv_info": (c_int, [C.POINTER(PackParams), C.POINTER(PackInfo)]),

@@ -37,7 +37,7 @@ enum dp_status {
   DP_ERR_LAUNCH = -3        /* hipGetLastError() after launch */
 };
 
-#define DP_ABI_VERSION 4
+#define DP_ABI_VERSION 5
 int dp_abi_version(void);
 /* human-readable reason of the last non-zero return on this thread */
 const char* dp_last_error(void);
@@ -336,6 +336,11 @@ int dp_broadcast_hw_nhwc(const void* in, void* out, int R, int HW, int C, int ou
 /* exclusive prefix sum of the per-image detection counts (fast_rcnn.py:86-140 keeps at most max_dets per image): offsets[i] = the
  * first row of image i in the compact ROI list, total[0] = R. One tiny launch instead of a read-back + host cumsum + upload. */
 int dp_count_offsets(const int32_t* counts, int n_img, int32_t* offsets, int32_t* total, dp_stream_t stream);
+/* (ABI 5) ... with the compact ROI list capped at `limit` rows: counts_out[i] = min(counts[i], limit - offsets[i]) (>= 0), offsets and
+ * total follow the capped counts. The DensePose branch (roi_head.py:126-158) is launched before the host knows R; its buffers are
+ * sized for a high-water mark of recent steps instead of n x DETECTIONS_PER_IMAGE slots, this cap keeps the device inside them, and the
+ * host - which reads the TRUE counts one step later anyway - runs the branch again with more slots in the rare step that overflowed. */
+int dp_count_offsets_limited(const int32_t* counts, int n_img, int limit, int32_t* counts_out, int32_t* offsets, int32_t* total, dp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Host-side weight pipeline (CPU code, no stream): canonical fp32 parameters -> the packed operands of
