@@ -45,6 +45,11 @@ CASES = {
     "full_r101_s1x_small": ("densepose_rcnn_R_101_FPN_s1x",
                             ["INPUT.MIN_SIZE_TEST", 256, "INPUT.MAX_SIZE_TEST", 448, "TEST.DETECTIONS_PER_IMAGE", 4],
                             7, 41, (256, 400), False, 4),
+    # BASELINE.json configs[0]'s model at FULL channel width: no decoder, the DensePose pooler over the four FPN levels at 14 x 14,
+    # 15 coarse channels (configs/densepose_rcnn_R_50_FPN_s1x_legacy.yaml:7-13), reduced frame
+    "full_r50_legacy_small": ("densepose_rcnn_R_50_FPN_s1x_legacy",
+                              ["INPUT.MIN_SIZE_TEST", 256, "INPUT.MAX_SIZE_TEST", 448, "TEST.DETECTIONS_PER_IMAGE", 4],
+                              8, 51, (256, 400), False, 4),
     # BASELINE.json configs[1] geometry: 800x1333 frame, R pinned to 8
     "full_r50_s1x_800x1333": ("densepose_rcnn_R_50_FPN_s1x", ["TEST.DETECTIONS_PER_IMAGE", 8], 0, 1234, (800, 1333), False, 8),
     # DeepLab head at its REAL geometry (densepose/config.py:177 POOLER_RESOLUTION 28; deeplab.py:33 rates 6 / 12 / 56):

@@ -93,7 +93,7 @@ def label_stats(r):
     return tot, diff, worst
 
 
-def run_forced(name, dtype):
+def run_forced(name, dtype, engine_opts=None):
     """Every dp_conv2d_nhwc launch (and GroupNorm) of the engine recorded, then the storage-emulating oracle run with teacher forcing
     (oracle/ref_storage.py) on the engine's detections: -> ({layer name: stats of oracle(engine's input) against the engine's output},
     stage_stats of the four IUV maps, label_stats)."""
@@ -107,6 +107,9 @@ def run_forced(name, dtype):
     # launches that fuse several layers are bit-identical to the layer-by-layer path (tests/test_gpu_kernels.py) and have no per-layer
     # outputs to record
     eng.fuse_stem_pool = eng.fuse_bottleneck = eng.fuse_rpn_head = False
+    for k, v in (engine_opts or {}).items():      # per-layer choices that move a rounding point (the oracle mirrors them)
+        assert hasattr(eng, k), k
+        setattr(eng, k, v)
     eng.keep_intermediates = True
     rec = {}
     conv0, gn0 = eng.conv, eng.groupnorm
