@@ -73,6 +73,41 @@ __global__ void resize_v_kernel(const uint8_t* __restrict__ tmp, uint8_t* __rest
   put4(dst + ((long long)blockIdx.z * 3 * oh + row) * ow, xo, ow, v);
 }
 
+// The vertical pass FUSED with rcnn.py:156-181 (normalise, zero-pad to a multiple of 32) and the paired-pixel layout the stem reads
+// (dp_ops.hip preprocess_paired_kernel): cell (n, y, j) of [n][Hp][Wq][8] = the 4-channel pixels 2j - 3 and 2j - 2 of row y. Same integer
+// expression as resize_v_kernel, same float expression as the preprocess kernel: bit-identical to the two launches it replaces, and the
+// resized uint8 batch [n][3][oh][ow] is neither written nor read back (frames whose scale is not 1, i.e. every video).
+template <typename T>
+__global__ void resize_v_preprocess_paired_kernel(const uint8_t* __restrict__ tmp, T* __restrict__ dst, int H, int oh, int ow, int Hp, int Wq,
+                                                  const int4* __restrict__ ytab, int prec, float m0, float m1, float m2, float s0, float s1, float s2) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, n = blockIdx.z;
+  if (j >= Wq) return;
+  float4 px[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  if (y < oh) {
+    const int4 e = ytab[y];
+    const uint8_t* __restrict__ t = tmp + (long long)n * 3 * H * ow;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int x = 2 * j + k - 3;
+      if (x >= 0 && x < ow) {
+        int v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const uint8_t* __restrict__ pl = t + (long long)c * H * ow;
+          const int r = (e.z * (int)pl[(long long)e.x * ow + x] + e.w * (int)pl[(long long)e.y * ow + x] + (1 << (prec - 1))) >> prec;
+          v[c] = r < 0 ? 0 : (r > 255 ? 255 : r);
+        }
+        px[k].x = ((float)v[0] - m0) / s0;
+        px[k].y = ((float)v[1] - m1) / s1;
+        px[k].z = ((float)v[2] - m2) / s2;
+      }
+    }
+  }
+  T* d = dst + (((long long)n * Hp + y) * Wq + j) * 8;
+  store4(d, px[0]);
+  store4(d + 4, px[1]);
+}
+
 // Bit-exact restatement of ATen's CPU upsample_bilinear2d (size= given, align_corners=False) as the reference's visualiser
 // calls it (visualizer.py:14-16,24-25): the vectorised CPU kernel evaluates
 //     src = fma(scale, dst + 0.5, -0.5) clamped at 0, scale = in / out in float;  i0 = min(int(src), n - 1);  l = src - i0
@@ -178,6 +213,44 @@ extern "C" int dp_resize_u8_bilinear_batch(const dp_resize_params* p, const void
   DP_REQUIRE(srcs && n >= 0, "dp_resize_u8_bilinear_batch: bad frame list");
   if (n == 0) return DP_OK;
   return resize_launch(p, srcs, n, as_stream(stream));
+}
+
+extern "C" int dp_resize_preprocess_u8_batch(const dp_resize_params* p, const void* const* srcs, int n, const dp_preprocess_params* q,
+                                             dp_stream_t stream) {
+  DP_REQUIRE(p && p->tmp && p->xtab && p->ytab && q && q->dst, "dp_resize_preprocess_u8_batch: null pointer");
+  DP_REQUIRE(p->H > 0 && p->W > 0 && p->oh > 0 && p->ow > 0 && p->xprec > 0 && p->xprec < 23 && p->yprec > 0 && p->yprec < 23,
+             "dp_resize_preprocess_u8_batch: bad resize parameters");
+  DP_REQUIRE(srcs && n > 0 && n <= kMaxResizeBatch, "dp_resize_preprocess_u8_batch: 1 .. %d frames per call", kMaxResizeBatch);
+  DP_REQUIRE(q->paired == 1 && q->n_img == n && q->h == p->oh && q->w == p->ow && q->Hp >= p->oh && q->Wp >= p->ow && q->Wp % 2 == 0 && q->Hp < 65536,
+             "dp_resize_preprocess_u8_batch: the preprocess parameters must describe the resized frames in the paired layout");
+  DP_REQUIRE(q->dtype == DP_F32 || q->dtype == DP_BF16 || q->dtype == DP_F16, "dp_resize_preprocess_u8_batch: bad dtype");
+  DP_REQUIRE(3ll * p->H < 65536, "dp_resize_preprocess_u8_batch: more than 21845 rows");
+  hipStream_t s = as_stream(stream);
+  ResizeSrcs a;
+  for (int i = 0; i < n; ++i) {
+    DP_REQUIRE(srcs[i], "dp_resize_preprocess_u8_batch: null frame %d", i);
+    a.p[i] = static_cast<const uint8_t*>(srcs[i]);
+  }
+  const int gx = (p->ow + 4 * 256 - 1) / (4 * 256);
+  const dim3 gh = p->src_hwc ? dim3((p->ow + 255) / 256, p->H, n) : dim3(gx, 3 * p->H, n);
+  hipLaunchKernelGGL(resize_h_kernel, gh, dim3(256), 0, s, a, p->tmp, p->H, p->W, p->ow, p->src_hwc, reinterpret_cast<const int4*>(p->xtab), p->xprec);
+  const int Wq = q->Wp / 2 + 3;
+  const dim3 gv((Wq + 255) / 256, q->Hp, n);
+  const int4* yt = reinterpret_cast<const int4*>(p->ytab);
+  switch (q->dtype) {
+    case DP_F32:
+      hipLaunchKernelGGL(resize_v_preprocess_paired_kernel<float>, gv, dim3(256), 0, s, p->tmp, (float*)q->dst, p->H, p->oh, p->ow, q->Hp, Wq, yt, p->yprec,
+                         q->mean[0], q->mean[1], q->mean[2], q->std[0], q->std[1], q->std[2]);
+      break;
+    case DP_BF16:
+      hipLaunchKernelGGL(resize_v_preprocess_paired_kernel<uint16_t>, gv, dim3(256), 0, s, p->tmp, (uint16_t*)q->dst, p->H, p->oh, p->ow, q->Hp, Wq, yt,
+                         p->yprec, q->mean[0], q->mean[1], q->mean[2], q->std[0], q->std[1], q->std[2]);
+      break;
+    default:
+      hipLaunchKernelGGL(resize_v_preprocess_paired_kernel<f16_t>, gv, dim3(256), 0, s, p->tmp, (f16_t*)q->dst, p->H, p->oh, p->ow, q->Hp, Wq, yt, p->yprec,
+                         q->mean[0], q->mean[1], q->mean[2], q->std[0], q->std[1], q->std[2]);
+  }
+  return dp_check_launch("resize_v_preprocess_paired_kernel");
 }
 
 extern "C" int dp_iuv_extract(const dp_iuv_extract_params* p, dp_stream_t stream) {

@@ -771,15 +771,30 @@ class Engine:
     # ------------------------------------------------------------------ whole path for a batch of equal-size frames
     def _phase_a(self, images_u8, given_boxes=None, hwc=False):
         """preprocess -> backbone -> RPN -> box head -> detection select (everything whose launch sizes are static)."""
-        assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[3 if hwc else 1] == 3
-        images_u8 = images_u8.contiguous()
-        if hwc:
-            n, h, w, _ = images_u8.shape
-        else:
+        from .resize import FusedResize
+        if isinstance(images_u8, tuple):
+            # ("x", paired-layout tensor, h, w): already resized + preprocessed (dp_resize_preprocess_u8_batch wrote it)
+            _, xt, h, w = images_u8
+            n = int(xt.shape[0])
+            Hp, Wp = round_up(h, 32), round_up(w, 32)
+            x = Act(xt, n, Hp, Wp // 2 + 3, 8)
+        elif isinstance(images_u8, FusedResize):
             n, _, h, w = images_u8.shape
-        Hp, Wp = round_up(h, 32), round_up(w, 32)
-        with self._stage("preprocess"):
-            x = self.preprocess(images_u8, Hp, Wp, hwc)
+            Hp, Wp = round_up(h, 32), round_up(w, 32)
+            with self._stage("preprocess"):
+                xt = self._empty((n, Hp, Wp // 2 + 3, 8))
+                images_u8.run(self, xt)
+            x = Act(xt, n, Hp, Wp // 2 + 3, 8)
+        else:
+            assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[3 if hwc else 1] == 3
+            images_u8 = images_u8.contiguous()
+            if hwc:
+                n, h, w, _ = images_u8.shape
+            else:
+                n, _, h, w = images_u8.shape
+            Hp, Wp = round_up(h, 32), round_up(w, 32)
+            with self._stage("preprocess"):
+                x = self.preprocess(images_u8, Hp, Wp, hwc)
         feats = self.backbone(x)
         if self.keep_intermediates:
             self.inter.update(feats)
@@ -845,12 +860,16 @@ class Engine:
         """Phase A + asynchronous read-back of the detection counts. With ``use_graphs`` the launch sequence of a given
         (sub-batch shape, stream slot) is captured once into a HIP graph and replayed: the ~200 kernel launches of the
         static part cost one graph launch on the host instead of ~200 x (ctypes call + hipLaunchKernel)."""
+        from .resize import FusedResize
         frames = None
-        if isinstance(images_u8, (list, tuple)):      # separate same-size device frames: gathered straight into the batch buffer
+        fused = images_u8 if isinstance(images_u8, FusedResize) else None
+        if fused is not None:
+            shape = ("fused",) + tuple(fused.shape)
+        elif isinstance(images_u8, (list, tuple)):      # separate same-size device frames: gathered straight into the batch buffer
             frames, shape = images_u8, (len(images_u8),) + tuple(images_u8[0].shape)
         else:
             shape = tuple(images_u8.shape)
-        n = shape[0]
+        n = shape[1] if fused is not None else shape[0]
         graphable = self.use_graphs and given_boxes is None and not self.keep_intermediates and self.prof is None and self.trace is None
         if not graphable:
             if frames is not None:
@@ -876,7 +895,15 @@ class Engine:
                     old = self._graphs.pop(next(iter(self._graphs)))
                     self._pinned.pop(old[5], None)
                     del old
-                static_in = torch.stack(frames) if frames is not None else images_u8.clone()
+                if fused is not None:
+                    # the graph starts BEHIND the fused resize + preprocess (the frame pointers change every step): its static input is
+                    # the paired-layout tensor that launch writes
+                    _, _, fh, fw = fused.shape
+                    xs = self._empty((n, round_up(fh, 32), round_up(fw, 32) // 2 + 3, 8))
+                    fused.run(self, xs)
+                    static_in = ("x", xs, fh, fw)
+                else:
+                    static_in = torch.stack(frames) if frames is not None else images_u8.clone()
                 self._phase_a(static_in, None, hwc)   # eager warm-up: one-time attribute / table initialisation outside capture
                 torch.cuda.current_stream(self.device).synchronize()
                 pinned = self._pinned_counts(key, n)
@@ -891,7 +918,9 @@ class Engine:
                 self.flops_last = flops0
             self._graphs[key] = entry                       # (re-)inserted last = most recently used
             graph, static_in, st, pinned, flops, _ = entry
-            if frames is not None:
+            if fused is not None:
+                fused.run(self, static_in[1])           # horizontal pass + (vertical pass, normalise, pad, layout) into the graph's input
+            elif frames is not None:
                 torch.stack(frames, out=static_in)      # one gather kernel: the frames land in the graph's input directly
             else:
                 static_in.copy_(images_u8, non_blocking=True)
@@ -979,7 +1008,8 @@ class Engine:
         num_streams > 1 splits the batch into that many sub-batches, each running the whole path on its own HIP stream:
         frames are independent, so the sub-batches' kernels fill each other's partial waves / tails and the
         detection-count read-back of one overlaps the other's kernels. Results are identical to num_streams=1."""
-        n = len(images_u8) if isinstance(images_u8, (list, tuple)) else images_u8.shape[0]
+        from .resize import FusedResize
+        n = len(images_u8) if isinstance(images_u8, (list, tuple)) else (images_u8.n if isinstance(images_u8, FusedResize) else images_u8.shape[0])
         self.flops_last = 0
         self.inter = {}
         g = max(1, min(int(num_streams), n)) if given_boxes is None else 1

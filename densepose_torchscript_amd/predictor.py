@@ -112,6 +112,8 @@ class DensePosePredictor:
         self._lanes, self._next_lane = [], 0
         self._last_done = []   # completion events of the most recent predict_batch call (one per frame group)
         self._host_ring = None  # _HostFrameRing, created on the first host-resident frame
+        import os as _os
+        self.fuse_resize = _os.environ.get("DP_FUSE_RESIZE", "1") != "0"   # device resize at scale != 1: fused with the preprocess (A/B knob)
 
     # -- defaults.py:76-89 ---------------------------------------------------------------------------------
     def _to_chw(self, original_image, bgr):
@@ -156,6 +158,10 @@ class DensePosePredictor:
             frames = [v.to(self.device, non_blocking=True) for v in views]
             if identity:
                 return [f.contiguous() for f in frames], True
+            if self.fuse_resize and self.num_streams == 1 and len(frames) <= 64:
+                # scale != 1 (every video frame): vertical pass + normalise + pad + layout in one launch, straight into the stem's input
+                from .resize import FusedResize
+                return FusedResize(self.engine, frames, k, src_hwc=hwc), False
             return resize_u8_device_batch(self.engine, frames, k, src_hwc=hwc), False
         # "host": torch's CPU uint8 kernel exactly as the reference runs it; the resized frames go up through the same ring
         small = [F.interpolate(c.cpu()[None], scale_factor=k, mode="bilinear", align_corners=False)[0] for c in chws]

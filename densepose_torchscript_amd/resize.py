@@ -82,3 +82,44 @@ def resize_u8_device_batch(engine, frames, k, src_hwc=False):
 def resize_u8_device(engine, img, k, src_hwc=False):
     """img: uint8 device tensor [3,H,W] (or [H,W,3] with src_hwc). Returns uint8 [3,oh,ow] on the device."""
     return resize_u8_device_batch(engine, [img], k, src_hwc)[0]
+
+
+class FusedResize:
+    """Frames of ONE geometry whose scale is not 1, to be resized AND preprocessed by dp_resize_preprocess_u8_batch: the engine calls
+    run(x) with the paired-layout tensor its stem reads ([n, Hp, Wp / 2 + 3, 8], engine.preprocess) - the horizontal pass, then one
+    launch for vertical pass + normalise + pad + layout; the resized uint8 batch is never materialised."""
+
+    def __init__(self, engine, frames, k, src_hwc):
+        self.frames = [f.contiguous() for f in frames]
+        f0 = self.frames[0]
+        self.src_hwc = bool(src_hwc)
+        self.H, self.W = (int(f0.shape[0]), int(f0.shape[1])) if src_hwc else (int(f0.shape[1]), int(f0.shape[2]))
+        assert all(f.shape == f0.shape and f.dtype == torch.uint8 and f.is_cuda for f in self.frames) and len(self.frames) <= 64
+        self.k = k
+        self.oh, self.ow = output_size(self.H, self.W, k)
+        self.n = len(self.frames)
+        self.shape = (self.n, 3, self.oh, self.ow)       # what the resized uint8 batch would be
+
+    def run(self, engine, x):
+        xt, px = axis_table(self.W, self.ow, self.k)
+        yt, py = axis_table(self.H, self.oh, self.k)
+        dev = engine.device
+        cache = engine.__dict__.setdefault("_resize_tables", {})
+        key = (self.H, self.W, self.oh, self.ow, self.k)
+        if key not in cache:
+            cache[key] = (torch.from_numpy(xt).to(dev), torch.from_numpy(yt).to(dev))
+        xtab, ytab = cache[key]
+        tmp = torch.empty((self.n, 3, self.H, self.ow), dtype=torch.uint8, device=dev)
+        p = L.ResizeParams()
+        p.src, p.tmp, p.dst = None, tmp.data_ptr(), None
+        p.H, p.W, p.oh, p.ow, p.src_hwc = self.H, self.W, self.oh, self.ow, 1 if self.src_hwc else 0
+        p.xtab, p.ytab, p.xprec, p.yprec = xtab.data_ptr(), ytab.data_ptr(), px, py
+        q = L.PreprocessParams()
+        Hp, Wq = int(x.shape[1]), int(x.shape[2])
+        q.src, q.dst, q.paired, q.src_hwc = None, x.data_ptr(), 1, 0
+        q.n_img, q.h, q.w, q.Hp, q.Wp, q.dtype = self.n, self.oh, self.ow, Hp, 2 * (Wq - 3), engine.dt
+        for i in range(3):
+            q.mean[i] = engine.cfg.pixel_mean[i]
+            q.std[i] = engine.cfg.pixel_std[i]
+        srcs = (C.c_void_p * self.n)(*[f.data_ptr() for f in self.frames])
+        L.check(engine.lib.dp_resize_preprocess_u8_batch(C.byref(p), srcs, self.n, C.byref(q), engine._stream()), "dp_resize_preprocess_u8_batch")

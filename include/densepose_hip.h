@@ -394,6 +394,11 @@ int dp_resize_u8_bilinear(const dp_resize_params* p, dp_stream_t stream);
 /* n frames of ONE geometry (a video, run.py:42-57) in one launch per pass: srcs = host array of n device pointers
  * (p->src is ignored), p->tmp = [n][3][H][ow], p->dst = [n][3][oh][ow] - the batch tensor the engine consumes. */
 int dp_resize_u8_bilinear_batch(const dp_resize_params* p, const void* const* srcs, int n, dp_stream_t stream);
+/* (ABI 5) defaults.py:84-89 + rcnn.py:156-181 for frames whose scale is not 1: the horizontal pass into p->tmp, then ONE launch that does
+ * the vertical pass, (x - mean) / std, the zero padding to q->Hp x q->Wp and the paired-pixel layout the stem reads (q->paired must be 1,
+ * q->h / q->w = p->oh / p->ow, q->n_img = n <= 64; q->src and p->dst are ignored): the resized uint8 batch is never written. Bit-identical
+ * to dp_resize_u8_bilinear_batch followed by dp_preprocess_u8. */
+int dp_resize_preprocess_u8_batch(const dp_resize_params* p, const void* const* srcs, int n, const dp_preprocess_params* q, dp_stream_t stream);
 
 typedef struct {
   const float* coarse; const float* fine; const float* u; const float* v; /* [R][C][S][S] */

@@ -579,6 +579,49 @@ def test_densepose_branch_slots_follow_the_detection_count(dtype):
             assert torch.equal(a[k].cpu(), b[k].cpu()), k
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
+def test_fused_resize_preprocess_equals_two_launches(dtype):
+    """SURVEY 8 f1 for frames whose scale is not 1 (1080 x 1920 video frames -> 749 x 1333, BASELINE.json configs[4]'s input):
+    the vertical resize pass, (x - mean) / std, the padding and the stem's paired layout in ONE launch (dp_resize_preprocess_u8_batch)
+    against the resize's two passes followed by the preprocess launch - the paired-layout tensor the stem reads, bit for bit, and the
+    end-to-end results of a batch with HIP graphs and pipeline lanes."""
+    import ctypes as C
+    from densepose_torchscript_amd import TINY_OPTS, get_config, make_synthetic_state
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    from densepose_torchscript_amd.resize import FusedResize, resize_u8_device_batch
+    cfg = get_config("densepose_rcnn_R_50_FPN_s1x", TINY_OPTS + ["INPUT.MIN_SIZE_TEST", 800, "INPUT.MAX_SIZE_TEST", 1333,
+                                                                 "MODEL.ROI_DENSEPOSE_HEAD.POOLER_RESOLUTION", 7])
+    state = make_synthetic_state(cfg, 2)
+    rng = np.random.default_rng(5)
+    frames = [torch.from_numpy(rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)).cuda() for _ in range(3)]
+    two = DensePosePredictor(cfg, state, dtype=dtype, resize="device")
+    two.fuse_resize = False
+    one = DensePosePredictor(cfg, state, dtype=dtype, resize="device", use_graphs=True, pipeline_depth=2)
+    assert one.fuse_resize
+    # the tensor the stem reads
+    e = one.engine
+    k = one._scale(1080, 1920)
+    u8 = resize_u8_device_batch(e, frames, k, src_hwc=True)
+    assert tuple(u8.shape) == (3, 3, 749, 1333)
+    want_x = e.preprocess(u8, 768, 1344)
+    fr = FusedResize(e, frames, k, src_hwc=True)
+    got_x = torch.full_like(want_x.t, 3.0)
+    fr.run(e, got_x)
+    torch.cuda.synchronize()
+    assert torch.equal(got_x, want_x.t)
+    # end to end, three times over (capture, replay, replay on the other lane)
+    want = two.predict_batch(frames)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        got = one.predict_batch(frames)
+        one.join()
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            for key in a:
+                assert torch.equal(a[key].cpu(), b[key].cpu()), key
+    assert sum(int(o["scores"].shape[0]) for o in want) > 0
+
+
 def test_video_frame_geometry_and_chw_input():
     """1080x1920 frame (-> 749x1333, padded 768x1344) given as CHW; same result as HWC."""
     from densepose_torchscript_amd import TINY_OPTS, get_config, make_synthetic_state
