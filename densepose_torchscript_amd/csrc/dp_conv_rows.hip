@@ -383,6 +383,263 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const RowsArgs p) 
 #undef DP_STAMP
 }
 
+// =====================================================================================================
+// The same arithmetic as a CHAIN with no workgroup barrier in the loop (round 4, second form). Phase stamps of the kernel above say a
+// step is 36 MFMAs per wave against ~1000 cycles of per-step fixed cost - the barrier that guards the staging buffer, the reduction of
+// the eight partial tiles, everything in lockstep behind that barrier. Here the eight K parts hand their accumulators ON instead:
+// wave h starts the accumulators of an output row from what wave h - 1 has summed over channel parts 0 .. h - 1 (a 2 KiB tile through
+// an LDS ring of HB slots per link, a produced / consumed counter pair per link polled with s_sleep), adds its own 576 K values over
+// three steps and passes the row to wave h + 1; wave 7 adds the bias, applies the activation and stores. Every wave runs at its own
+// pace, two rows behind its predecessor; the two waves of a SIMD drift apart by themselves and fill each other's issue gaps.
+// Per output pixel: one fp32 MFMA chain over K in the order channel part, kernel row, 32-channel block, kernel column - fixed,
+// independent of strip, lane, workgroup and batch (again NOT the LDS-ring kernels' order).
+// =====================================================================================================
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv3x3_chain_kernel(const RowsArgs p) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int CIN = 512, NCT = 2, KPW = 64, NCB = 2, PPW = KPW * 2 + 32, NPX = 19, NP = 3, ROWB = NP * 1024, D = 3, NSLOT = D + 1;
+  constexpr int NF = NCB * 3;
+  constexpr int RING = 8 * NSLOT * ROWB;
+  constexpr int HB = 4, HSLOT = NCT * 1024;     // hand-over ring: HB tiles of [cout tile][lane] x 16 B per link
+  constexpr int HAND = RING, ZERO = HAND + 7 * HB * HSLOT, TRASH = ZERO + HSLOT, FLAGS = TRASH + HSLOT;
+  constexpr int OOB = (int)0x80000000;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // = K part h
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.x;
+  const int slice = (b >> 3) % p.n_slices;
+  const int pg = (b & 7) + 8 * (b / (8 * p.n_slices));
+
+  const int n_live = p.n_dev ? min(*p.n_dev, p.N) : p.N;
+  const int n_strips = ((n_live + p.G - 1) / p.G) * p.SPG;
+  const long long TR = (long long)n_strips * p.H;
+  const int wa = (int)(TR * pg / p.n_pg), wb = (int)(TR * (pg + 1) / p.n_pg);
+  if (wb <= wa) return;
+
+  u32x4 wfr[NCT * NCB * 9];
+  {
+    const int n_planes = p.kpad * 2 / 64;
+    const unsigned char* __restrict__ wp = reinterpret_cast<const unsigned char*>(p.w);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int cbl = 0; cbl < NCB; ++cbl)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          wfr[(ct * NCB + cbl) * 9 + t] =
+              *reinterpret_cast<const u32x4*>(wp + dp_wtile_off(slice * NCT * 16 + ct * 16 + fr, (wave * NCB + cbl) * 9 + t, fq, n_planes));
+  }
+  const int cout0 = slice * NCT * 16;
+  float bias8[8];
+  {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + cout0 + fq * 8), b1 = *reinterpret_cast<const f32x4*>(p.bias + cout0 + fq * 8 + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { bias8[k] = b0[k]; bias8[4 + k] = b1[k]; }
+  }
+  // counters + the zero tile (hand-over source of rows that start here or are never finished)
+  volatile int* const flagP = reinterpret_cast<volatile int*>(smem + FLAGS);        // P[h]: rows wave h has handed on
+  volatile int* const flagC = flagP + 8;                                             // C[h]: rows wave h has taken over
+  if (tid < 16) flagP[tid] = 0;
+  for (int i = tid; i < HSLOT / 16; i += 512) reinterpret_cast<u32x4*>(smem + ZERO)[i] = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const int in_row = p.W * CIN * 2, out_row = p.W * p.opitch * 2;
+
+  auto decode = [&](int strip, int& img0, int& c00, int& len0) __attribute__((always_inline)) {
+    const int grp = strip / p.SPG, k = strip - grp * p.SPG;
+    const int x0 = k * 16, ig = x0 / p.W;
+    c00 = x0 - ig * p.W;
+    img0 = grp * p.G + ig;
+    len0 = min(16, p.W - c00);
+  };
+  int f_boff[3];
+  auto setup_fetch = [&](int strip) __attribute__((always_inline)) {
+    int img0, c00, len0;
+    decode(strip, img0, c00, len0);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) {
+      const int o = pc * 1024 + lane * 16;
+      const int j = o / PPW, wbyte = o - j * PPW;
+      const bool seg1 = j >= len0 + 2;
+      const int col = seg1 ? j - (len0 + 2) : c00 - 1 + j;
+      const int img = img0 + (seg1 ? 1 : 0);
+      const bool ok = j < NPX && wbyte < KPW * 2 && (unsigned)col < (unsigned)p.W && img < n_live && (!seg1 || len0 < 16);
+      f_boff[pc] = ok ? ((img * p.H * p.W + col) * CIN + wave * KPW) * 2 + wbyte : OOB;
+    }
+  };
+  int c_frag_n = 0, ob_n = OOB, ob_c = OOB;      // next step's fragment lane offset; output lane offsets of the next / this step's strip
+  auto setup_comp = [&](int strip) __attribute__((always_inline)) {
+    int img0, c00, len0;
+    decode(strip, img0, c00, len0);
+    const bool in1 = fr >= len0;
+    c_frag_n = (fr + (in1 ? 1 : 0)) * PPW + fq * 16;
+    const int img = img0 + (in1 ? 1 : 0), col = in1 ? fr - len0 : c00 + fr;
+    ob_n = img < n_live ? ((img * p.H * p.W + col) * p.opitch + cout0 + fq * 8) * 2 : OOB;
+  };
+  auto seg_init = [&](RowsIt& it, int strip) __attribute__((always_inline)) {
+    it.strip = strip;
+    it.r_lo = max(wa - strip * p.H, 0);
+    it.r_hi = min(wb - strip * p.H, p.H);
+    it.q = it.r_lo - 1;
+  };
+  const int s_first = wa / p.H, s_last = (wb - 1) / p.H;
+  const int n_steps = (wb - wa) + 2 * (s_last - s_first + 1);
+
+  unsigned char* const ring_w = smem + wave * (NSLOT * ROWB);
+  RowsIt it_f, it_n;
+  seg_init(it_f, s_first);
+  seg_init(it_n, s_first);
+  setup_fetch(s_first);
+  setup_comp(s_first);
+  int f_left = n_steps, f_slot = 0, f_roff = it_f.q * in_row;
+  auto fetch_next = [&]() __attribute__((always_inline)) {
+    const bool row_ok = f_left > 0 && (unsigned)it_f.q < (unsigned)p.H;
+    const int roff = row_ok ? f_roff : OOB;      // (a row that is zero padding or past the end: every valid lane out of range; nobody multiplies it)
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(ring_w + f_slot + pc * 1024), 16, f_boff[pc] + roff, 0, 0, 0);
+    f_slot = f_slot == (NSLOT - 1) * ROWB ? 0 : f_slot + ROWB;
+    if (f_left > 0) {
+      --f_left;
+      if (it_f.q == it_f.r_hi) {
+        if (it_f.strip < s_last) { seg_init(it_f, it_f.strip + 1); setup_fetch(it_f.strip); f_roff = it_f.q * in_row; }
+      } else {
+        ++it_f.q;
+        f_roff += in_row;
+      }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) fetch_next();
+
+  f32x4 acc[3][NCT];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[a][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 bf[NF];
+  int c_q = it_n.q, c_rlo = it_n.r_lo, c_rhi = it_n.r_hi;
+  int n_slot = 0;
+  int e_in = 0, e_out = 0;                       // rows taken over from wave h - 1 / handed on to wave h + 1 so far
+  unsigned char* const hand_in = smem + HAND + (wave - 1) * (HB * HSLOT) + lane * 16;      // (wave 0 never uses it)
+  unsigned char* const hand_out = smem + HAND + wave * (HB * HSLOT) + lane * 16;
+  // a bounded wait: a protocol error must not hang the GPU (the result is then wrong and the tests say so)
+  auto wait_ge = [&](volatile int* f, int v) __attribute__((always_inline)) {
+    int spins = 0;
+    while (*f < v && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); ++spins; }
+  };
+
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // the first row has landed
+  {
+    const unsigned char* const row = ring_w + c_frag_n;
+    static_for<0, NF>([&](auto ff) { constexpr int f = decltype(ff)::value; bf[f] = *reinterpret_cast<const u32x4*>(row + (f % 3) * PPW + (f / 3) * 64); });
+  }
+
+  auto step = [&](auto ph_c, int s) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph_c)::value;
+    constexpr int A_OLD = (PH + 2) % 3, A_MID = PH, A_NEW = (PH + 1) % 3;
+    if (s > 0) { c_q = it_n.q; c_rlo = it_n.r_lo; c_rhi = it_n.r_hi; }
+    ob_c = ob_n;
+    if (s + 1 < n_steps) {
+      if (it_n.q == it_n.r_hi) {
+        if (it_n.strip < s_last) { seg_init(it_n, it_n.strip + 1); setup_comp(it_n.strip); }
+      } else {
+        ++it_n.q;
+      }
+    }
+    n_slot = n_slot == (NSLOT - 1) * ROWB ? 0 : n_slot + ROWB;
+    const bool row_ok = (unsigned)c_q < (unsigned)p.H;
+    const bool need_in = wave > 0 && c_q + 1 >= c_rlo && c_q + 1 < c_rhi;      // the row that starts in this step comes from wave h - 1
+    const bool emit = c_q - 1 >= c_rlo;                                        // the row that is complete after this step goes on
+    if (need_in) wait_ge(flagP + wave - 1, e_in + 1);
+    asm volatile("" ::: "memory");
+    const unsigned char* const hin = need_in ? hand_in + (e_in & (HB - 1)) * HSLOT : smem + ZERO + lane * 16;
+    fetch_next();                                  // row of step s + D -> the ring slot of step s - 1
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    auto mma = [&](auto ff, auto ky_c, f32x4 (&a)[NCT]) __attribute__((always_inline)) {
+      constexpr int f = decltype(ff)::value, ky = decltype(ky_c)::value;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) Mma<T>::run(wfr[(ct * NCB + f / 3) * 9 + ky * 3 + f % 3], bf[f], a[ct]);
+    };
+    const unsigned char* const row_n = ring_w + n_slot + c_frag_n;
+    if (row_ok) {
+      // one straight-line block (a branch between two groups makes hipcc wait for every LDS read in flight at the block edge)
+      f32x4 hv[NCT];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) hv[ct] = *reinterpret_cast<const f32x4*>(hin + ct * 1024);
+      static_for<0, NF>([&](auto ff) { mma(ff, K2{}, acc[A_OLD]); });
+      static_for<0, NF>([&](auto ff) { mma(ff, K1{}, acc[A_MID]); });
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[A_NEW][ct] = hv[ct];
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // the row of step s + 1 has landed (rows s + 2, s + 3 and this wave's stores may be in flight)
+      static_for<0, NF>([&](auto ff) {
+        constexpr int f = decltype(ff)::value;
+        mma(ff, K0{}, acc[A_NEW]);
+        bf[f] = *reinterpret_cast<const u32x4*>(row_n + (f % 3) * PPW + (f / 3) * 64);
+      });
+    } else {
+      // a zero-padding row: nothing to multiply; the starting row still takes over its partial sums
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[A_NEW][ct] = *reinterpret_cast<const f32x4*>(hin + ct * 1024);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      static_for<0, NF>([&](auto ff) { constexpr int f = decltype(ff)::value; bf[f] = *reinterpret_cast<const u32x4*>(row_n + (f % 3) * PPW + (f / 3) * 64); });
+    }
+    if (need_in) {
+      // (the tile has been read: LDS executes a wave's instructions in order, the counter store follows the reads)
+      asm volatile("" ::: "memory");
+      ++e_in;
+      flagC[wave] = e_in;
+    }
+    if (emit) {
+      if (wave < 7) {
+        wait_ge(flagC + wave + 1, e_out - (HB - 1));                // the slot's previous tile has been taken over
+        asm volatile("" ::: "memory");
+        unsigned char* const ho = hand_out + (e_out & (HB - 1)) * HSLOT;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) *reinterpret_cast<f32x4*>(ho + ct * 1024) = acc[A_OLD][ct];
+        asm volatile("" ::: "memory");
+        ++e_out;
+        flagP[wave] = e_out;
+      } else {
+        u32x4 pk;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float x0 = acc[A_OLD][k >> 1][(2 * k) & 3] + bias8[2 * k], x1 = acc[A_OLD][k >> 1][(2 * k + 1) & 3] + bias8[2 * k + 1];
+          if (p.relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+          pk[k] = Elem<T>::pack2(x0, x1);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, ob_c + (c_q - 1) * out_row, 0, 0);
+      }
+    }
+  };
+  for (int s = 0; s < n_steps; s += 3) {
+    step(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < n_steps) step(std::integral_constant<int, 1>{}, s + 1);
+    if (s + 2 < n_steps) step(std::integral_constant<int, 2>{}, s + 2);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy fetches behind the last step still target this workgroup's LDS
+}
+
+template <typename T>
+int launch_chain(const RowsArgs& a, hipStream_t stream) {
+  constexpr int lds = 8 * 4 * 3072 + 7 * 4 * 2048 + 2 * 2048 + 64;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_chain_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_chain_kernel<T>), dim3(a.n_pg * a.n_slices), dim3(512), lds, stream, a);
+  return dp_check_launch("conv3x3_chain_kernel");
+}
+
 template <typename T, int CIN, int NCT>
 int launch_rows_r(const RowsArgs& a, hipStream_t stream) {
   constexpr int KPW = CIN / 8, PPW = KPW * 2 + 32, NP = (19 * PPW + 1023) / 1024;
@@ -477,5 +734,7 @@ int dp_conv_rows_launch(const dp_conv_params* p, dp_stream_t stream) {
   a.in_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cin * 2);
   a.out_bytes = (unsigned)((long long)p->N * p->H * p->W * p->osW * 2);
   hipStream_t s = as_stream(stream);
+  const char* ce = getenv("DP_CONV_ROWS_CHAIN");     // A/B knob: 1 = the barrier-free chain form for the 512-channel layers
+  if (p->Cin == 512 && ce && atoi(ce) == 1) return p->dtype == DP_BF16 ? launch_chain<uint16_t>(a, s) : launch_chain<f16_t>(a, s);
   return p->dtype == DP_BF16 ? launch_rows<uint16_t>(a, p->Cin, s) : launch_rows<f16_t>(a, p->Cin, s);
 }

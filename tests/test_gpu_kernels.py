@@ -512,9 +512,10 @@ ROWS_CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", ["rows", "chain"])     # chain: the barrier-free form of the 512-channel kernel (DP_CONV_ROWS_CHAIN=1, an A/B knob)
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", ROWS_CASES)
-def test_conv3x3_rows_kernel(eng, dt, case, monkeypatch):
+def test_conv3x3_rows_kernel(eng, dt, case, variant, monkeypatch):
     """The row-streaming K-split weight-stationary 3x3 kernel (dp_conv_rows.hip, kernel class 7: the DensePose head's
     body_conv_fcn1..8, v1convx.py:44-59 / deeplab.py:64-74, and res5's conv2, resnet.py:195-197) against torch in fp64 on operands
     rounded to the storage type, against the LDS-ring kernel (same products, another summation order), and against itself image by
@@ -525,6 +526,12 @@ def test_conv3x3_rows_kernel(eng, dt, case, monkeypatch):
     from densepose_torchscript_amd.pack import conv_from_oihw
     e = eng[dt]
     Ci, Co, N, H, W, live, relu = case
+    if variant == "chain":
+        if Ci != 512:
+            pytest.skip("the chain form exists for 512 input channels")
+        monkeypatch.setenv("DP_CONV_ROWS_CHAIN", "1")
+    else:
+        monkeypatch.delenv("DP_CONV_ROWS_CHAIN", raising=False)
     monkeypatch.setenv("DP_CONV_ROWS", "2")     # every shape the kernel takes (default policy: 512 input channels, no device-side count)
     g = torch.Generator().manual_seed(Ci + Co + N * 1000 + H * 10 + W)
     x = _round(torch.randn((N, Ci, H, W), generator=g), dt)
