@@ -26,7 +26,7 @@ def run(n=30):
     for _ in range(n): e.conv(layer, xa, relu=True)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for mode in ("1", "0", "1", "0"):
+for mode in (os.environ.get("ROWS_ON", "1"), "0") * 2:
     os.environ["DP_CONV_ROWS"] = mode
     ms = run()
     print("R=%d %dx%d %d->%d %s DP_CONV_ROWS=%s: %.1f us  %.0f TFLOP/s (%.3f of 2.5 PF)" % (R, H, W, Ci, Co, dt, mode, ms * 1e3, flops / ms / 1e9, flops / ms / 1e9 / 2500))
