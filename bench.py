@@ -12,6 +12,7 @@ A "step" = one pass of the whole path (device resize -> backbone -> RPN -> box h
 over one batch of synthetic frames that are already resident in HBM. Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -373,7 +374,7 @@ def main():
     dflops, dsec, dcalls = agg[dom]
     peak = PEAK_F32_MATRIX if args.dtype == "fp32" else PEAK_BF16_DENSE  # fp16 and bf16 MFMA share the dense peak
     traffic = None
-    for tname in ("r3_hbm_traffic.json", "r2_hbm_traffic.json", "r1_hbm_traffic.json"):   # newest committed PMC summary that has this kernel
+    for tname in sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json"))), reverse=True):   # newest committed PMC summary that has this kernel
         tpath = os.path.join(ROOT, "profiles", tname)
         if traffic is None and os.path.exists(tpath) and args.dtype == "bf16" and args.config == "densepose_rcnn_R_50_FPN_s1x" and args.batch == 8:
             k = json.load(open(tpath))["kernels"].get(dom + "[bf16]")
