@@ -126,6 +126,7 @@ bool dp_conv_wsr_ok(const dp_conv_params* p);
 int dp_conv_wsr_launch(const dp_conv_params* p, dp_stream_t stream);
 // dp_conv_rows.hip: the row-streaming K-split weight-stationary 3x3 kernel (512 / 256 input channels) behind dp_conv2d_nhwc (kernel class 7)
 bool dp_conv_rows_ok(const dp_conv_params* p);
+bool dp_conv_rows2_ok(const dp_conv_params* p);     // its 32-pixel form (kernel class 8)
 int dp_conv_rows_launch(const dp_conv_params* p, dp_stream_t stream);
 
 // Packed weight matrices are stored in 1 KiB TILES of 16 rows x 64 bytes of K (round 3): tile (rg, plane) of a matrix with

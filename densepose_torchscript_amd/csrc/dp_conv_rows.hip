@@ -58,6 +58,7 @@ struct RowsArgs {
   int n_slices, n_pg;          // cout slices, pixel groups (grid = n_slices * n_pg workgroups)
   unsigned in_bytes, out_bytes;
   unsigned long long* dbg;     // diagnostic builds (-DDP_ROWS_EXP=16): per-wave phase cycle sums
+  int lockstep;                // conv3x3_rows2_kernel: 1 = all eight waves on one schedule (A/B knob), 0 = the two halves in opposite phases
 };
 
 template <int N>
@@ -627,6 +628,368 @@ __global__ __launch_bounds__(512, 2) void conv3x3_chain_kernel(const RowsArgs p)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy fetches behind the last step still target this workgroup's LDS
 }
 
+// =====================================================================================================
+// Third form (round 4): 32 pixels per step, waves = 4 K quarters x 2 cout halves. The two forms above spend ~1000 cycles per step on
+// work that does not grow with the matrix work (LDS-DMA issue, reduction, bookkeeping, barrier skew) against 36 MFMAs per wave. Here
+//   * wave (kq, ch) holds the weights of input channels [128 kq, 128 kq + 128) x 9 taps x the 16 couts of half ch: the same 36 A
+//     fragments = 144 VGPRs; a step is one input row of a 32-PIXEL strip = two pixel tiles = 72 MFMAs per wave;
+//   * the two waves of a K quarter read the SAME staged row slice (35 pixels x 256 B, 272-byte pixel pitch) from a ring they fill
+//     together (five 1 KiB LDS-DMA pieces each per step instead of 2 x 3 for the same pixels); four partial sums per output, not eight;
+//   * the quarters 0 / 1 live in waves 0 .. 3, 2 / 3 in waves 4 .. 7, and the two waves of a SIMD (w, w + 4) belong to different
+//     quarters: with the barrier in different places for the two halves (waves 0 .. 3: A B |, waves 4 .. 7: A | B) a SIMD's waves
+//     are in opposite phases, and every ring is produced and consumed by waves of ONE half, i.e. in lockstep;
+//   * fragments are read three at a time (one 32-channel block of one pixel tile, double buffered) between the MFMA groups: the
+//     accumulators (3 roles x 2 pixel tiles) and two fragment buffers are 48 registers beside the weights.
+// Strips are cut from the concatenated columns of G = 32 / gcd(W, 32) images (28-wide ROI maps: 8 ROIs = 224 columns = 7 strips); a
+// strip is at most two segments with one shared zero pixel between them (34 or 35 staged pixels).
+// Per output pixel: partial sum of quarter kq = kernel row, 32-channel block, kernel column (one fp32 MFMA chain); the four partials
+// are added in quarter order. Fixed, independent of strip, lane, workgroup and batch - and different from the two forms above and from
+// the LDS-ring kernels: which form a layer takes is decided by its geometry alone (dp_conv_rows_launch).
+// =====================================================================================================
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int CIN = 512, KPQ = 128, NCB = 4, PPW = KPQ * 2 + 16, NPX = 35;
+  constexpr int ROWB = NPX * PPW;               // 9520 bytes: nine whole 1 KiB pieces and 19 lanes of a tenth
+  constexpr int NPW = 5;                        // pieces per wave and row (wave ch = 0: pieces 0 .. 4, ch = 1: 5 .. 9)
+  constexpr int D = 2, NSLOT = 3;
+  constexpr int RING = 4 * NSLOT * ROWB;
+  constexpr int STGB = 16 * 1024;               // staging bytes per parity: [kq][ch][pixel tile][lane] x 16 B
+  constexpr int OOB = (int)0x80000000;
+  static_assert(ROWB % 16 == 0 && RING + 3 * STGB <= 160 * 1024, "LDS budget");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int ch = wave & 1, kq = 2 * (wave >> 2) + ((wave >> 1) & 1);
+  const int b = blockIdx.x;
+  const int slice = (b >> 3) % p.n_slices;
+  const int pg = (b & 7) + 8 * (b / (8 * p.n_slices));
+
+  const int n_live = p.n_dev ? min(*p.n_dev, p.N) : p.N;
+  const int n_strips = ((n_live + p.G - 1) / p.G) * p.SPG;
+  const long long TR = (long long)n_strips * p.H;
+  const int wa = (int)(TR * pg / p.n_pg), wb = (int)(TR * (pg + 1) / p.n_pg);
+  if (wb <= wa) return;
+
+  // ---- this wave's weights: cout tile ch of the slice x 4 channel blocks of quarter kq x 9 taps
+  u32x4 wfr[NCB * 9];
+  {
+    const int n_planes = p.kpad * 2 / 64;
+    const unsigned char* __restrict__ wp = reinterpret_cast<const unsigned char*>(p.w);
+#pragma unroll
+    for (int cbl = 0; cbl < NCB; ++cbl)
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        wfr[cbl * 9 + t] = *reinterpret_cast<const u32x4*>(wp + dp_wtile_off(slice * 32 + ch * 16 + fr, (kq * NCB + cbl) * 9 + t, fq, n_planes));
+  }
+  const int cout0 = slice * 32;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const int in_row = p.W * CIN * 2, out_row = p.W * p.opitch * 2;
+
+  auto decode = [&](int strip, int& img0, int& c00, int& len0) __attribute__((always_inline)) {
+    const int grp = strip / p.SPG, k = strip - grp * p.SPG;
+    const int x0 = k * 32, ig = x0 / p.W;
+    c00 = x0 - ig * p.W;
+    img0 = grp * p.G + ig;
+    len0 = min(32, p.W - c00);
+  };
+
+  // ---- fetch side: this lane's part of the wave's five pieces of a row slice
+  int f_boff[5];
+  const bool f_last = (ch * NPW + NPW - 1) * 1024 + lane * 16 < ROWB;       // the row's tenth piece is 19 lanes wide
+  auto setup_fetch = [&](int strip) __attribute__((always_inline)) {
+    int img0, c00, len0;
+    decode(strip, img0, c00, len0);
+#pragma unroll
+    for (int pc = 0; pc < NPW; ++pc) {
+      const int o = (ch * NPW + pc) * 1024 + lane * 16;
+      const int j = o / PPW, wbyte = o - j * PPW;
+      const bool seg1 = j >= len0 + 2;
+      const int col = seg1 ? j - (len0 + 2) : c00 - 1 + j;
+      const int img = img0 + (seg1 ? 1 : 0);
+      const bool ok = j < NPX && wbyte < KPQ * 2 && (unsigned)col < (unsigned)p.W && img < n_live && (!seg1 || len0 < 32);
+      f_boff[pc] = ok ? ((img * p.H * p.W + col) * CIN + kq * KPQ) * 2 + wbyte : OOB;
+    }
+  };
+  unsigned char* const ring_q = smem + kq * (NSLOT * ROWB);
+  unsigned char* const ring_wv = ring_q + ch * (NPW * 1024);
+
+  // ---- compute side: lane (fr, fq) = output pixels fr and 16 + fr of the strip
+  // ---- reduce side: wave w adds up the four partial sums of pixel tile w >> 2: lane l takes TWO consecutive output channels of pixel
+  // (l & 31) >> 1 in cout half (w & 1), channel quad 2 * ((w >> 1) & 1) + (l >> 5)
+  const int r_pt = wave >> 2, r_ch = wave & 1;
+  const int r_px = (lane & 31) >> 1, r_fq = 2 * ((wave >> 1) & 1) + (lane >> 5), r_half = lane & 1;
+  const int r_lds = (r_ch * 2 + r_pt) * 1024 + (r_fq * 16 + r_px) * 16 + r_half * 8;
+  float r_bias[2];
+  r_bias[0] = p.bias[cout0 + r_fq * 8 + r_ch * 4 + r_half * 2];
+  r_bias[1] = p.bias[cout0 + r_fq * 8 + r_ch * 4 + r_half * 2 + 1];
+  int c_frag[2] = {0, 0};
+  int r_obase = OOB;
+  auto setup_comp = [&](int strip) __attribute__((always_inline)) {
+    int img0, c00, len0;
+    decode(strip, img0, c00, len0);
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) {
+      const int px = pt * 16 + fr;
+      c_frag[pt] = (px + (px >= len0 ? 1 : 0)) * PPW + fq * 16;
+    }
+    const int px = r_pt * 16 + r_px;
+    const bool in1 = px >= len0;
+    const int img = img0 + (in1 ? 1 : 0), col = in1 ? px - len0 : c00 + px;
+    r_obase = img < n_live ? ((img * p.H * p.W + col) * p.opitch + cout0 + r_fq * 8 + r_ch * 4 + r_half * 2) * 2 : OOB;
+  };
+
+  auto seg_init = [&](RowsIt& it, int strip) __attribute__((always_inline)) {
+    it.strip = strip;
+    it.r_lo = max(wa - strip * p.H, 0);
+    it.r_hi = min(wb - strip * p.H, p.H);
+    it.q = it.r_lo - 1;
+  };
+  const int s_first = wa / p.H, s_last = (wb - 1) / p.H;
+  const int n_steps = (wb - wa) + 2 * (s_last - s_first + 1);
+
+  RowsIt it_f, it_c;
+  seg_init(it_f, s_first);
+  seg_init(it_c, s_first);
+  setup_fetch(s_first);
+  setup_comp(s_first);
+  int f_left = n_steps, f_slot = 0;
+  auto fetch_next = [&]() __attribute__((always_inline)) {
+    const bool row_ok = f_left > 0 && (unsigned)it_f.q < (unsigned)p.H;     // rows -1 and H and the rows behind the end: zeros
+    const int roff = it_f.q * in_row;
+    unsigned char* const dst = ring_wv + f_slot;
+    const bool issue = !(DP_ROWS_EXP & 1) || f_left > n_steps - 2;
+#pragma unroll
+    for (int pc = 0; pc < NPW - 1; ++pc)
+      if (issue) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(dst + pc * 1024), 16, row_ok ? f_boff[pc] + roff : OOB, 0, 0, 0);
+    if (f_last && issue)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(dst + (NPW - 1) * 1024), 16, row_ok ? f_boff[NPW - 1] + roff : OOB, 0, 0, 0);
+    f_slot = f_slot == (NSLOT - 1) * ROWB ? 0 : f_slot + ROWB;
+    if (f_left > 0) {
+      --f_left;
+      if (it_f.q == it_f.r_hi) {
+        if (it_f.strip < s_last) { seg_init(it_f, it_f.strip + 1); setup_fetch(it_f.strip); }
+      } else {
+        ++it_f.q;
+      }
+    }
+  };
+
+  f32x4 acc[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) acc[a][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  unsigned char* const stg = smem + RING;
+  unsigned char* const stg_w = stg + ((kq * 2 + ch) * 2) * 1024 + lane * 16;
+
+  // the row step s finished: four partial tiles in staging parity s % 3 -> bias, activation, one 4-byte store per lane. ALWAYS one
+  // store per step (out of range when there is nothing to store: the hardware drops it) - the counted vmcnt waits below rely on it.
+  // In two halves: the four LDS reads are issued at the top of phase A, the sums are taken after the step's LDS-DMA issue.
+  f32x2 rv[4];
+  auto reduce_issue = [&](int par) __attribute__((always_inline)) {
+    const unsigned char* const sr = stg + par * STGB + r_lds;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      if constexpr (DP_ROWS_EXP & 2) rv[q4] = f32x2{1.f, 2.f};
+      else rv[q4] = *reinterpret_cast<const f32x2*>(sr + q4 * 4096);
+    }
+  };
+  auto reduce_finish = [&](int t, int obase, bool emit) __attribute__((always_inline)) {
+    float x0 = rv[0][0], x1 = rv[0][1];
+#pragma unroll
+    for (int q4 = 1; q4 < 4; ++q4) { x0 += rv[q4][0]; x1 += rv[q4][1]; }     // quarter order: the summation order of a pixel is fixed
+    x0 += r_bias[0];
+    x1 += r_bias[1];
+    if (p.relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+    __builtin_amdgcn_raw_buffer_store_b32(Elem<T>::pack2(x0, x1), rs_out, (emit && !(DP_ROWS_EXP & 2)) ? obase + t * out_row : OOB, 0, 0);
+  };
+
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tl = (DP_ROWS_EXP & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+#define DP_STAMP(k) if constexpr (DP_ROWS_EXP & 16) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - tl; tl = t_; }
+  const bool sched_y = wave >= 4 || p.lockstep;      // barrier between phase A and phase B (else behind phase B)
+  // history of the two previous steps (the row of step s - 2 is complete in the staging buffer when phase A of step s starts)
+  bool p1_emit = false, p2_emit = false;
+  int p1_t = 0, p2_t = 0, p1_ob = OOB, p2_ob = OOB;
+  int c_slot = 0, c_par = 0;                          // ring slot / staging parity of step s
+  // bookkeeping of step s around the reduction of the row step s - 2 finished (staging parity (s - 2) % 3: complete since the last
+  // barrier, overwritten after the next one - so every wave reduces BEFORE its next barrier)
+  auto phase_a = [&](int s) __attribute__((always_inline)) {
+    reduce_issue(c_par == 0 ? 2 : c_par - 1);         // (the previous step's parity + 2) % 3, before c_par moves on
+    if (s > 0) {
+      p2_emit = p1_emit; p2_t = p1_t; p2_ob = p1_ob;
+      p1_t = it_c.q - 1;
+      p1_emit = p1_t >= it_c.r_lo;
+      p1_ob = r_obase;
+      if (it_c.q == it_c.r_hi) {
+        if (it_c.strip < s_last) { seg_init(it_c, it_c.strip + 1); setup_comp(it_c.strip); }
+      } else {
+        ++it_c.q;
+      }
+      c_slot = c_slot == (NSLOT - 1) * ROWB ? 0 : c_slot + ROWB;
+      c_par = c_par == 2 ? 0 : c_par + 1;
+    }
+    DP_STAMP(0)
+  };
+  u32x4 bf[2][3];
+  auto phase_b = [&](auto ph_c, int s) __attribute__((always_inline)) {
+    constexpr int PH = decltype(ph_c)::value;
+    constexpr int A_OLD = (PH + 2) % 3, A_MID = PH, A_NEW = (PH + 1) % 3;
+    const bool row_ok = (unsigned)it_c.q < (unsigned)p.H;
+    const unsigned char* const row0 = ring_q + c_slot + c_frag[0];
+    const unsigned char* const row1 = ring_q + c_slot + c_frag[1];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) acc[A_NEW][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row_ok) {
+      // one straight-line block: batch (pixel tile, channel block) = 3 fragments = 9 MFMAs, the next batch's reads issued first
+      auto ld = [&](auto bb) __attribute__((always_inline)) {
+        constexpr int bi = decltype(bb)::value, pt = bi >> 2, cb = bi & 3;
+        const unsigned char* const r = pt ? row1 : row0;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          if constexpr (DP_ROWS_EXP & 8) bf[bi & 1][kx] = u32x4{(unsigned)lane, (unsigned)bi, 1u, 2u};
+          else bf[bi & 1][kx] = *reinterpret_cast<const u32x4*>(r + kx * PPW + cb * 64);
+        }
+      };
+      ld(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_s_setprio(1);
+      static_for<0, 8>([&](auto bb) {
+        constexpr int bi = decltype(bb)::value, pt = bi >> 2, cb = bi & 3;
+        // (fenced: left alone hipcc moves each read down to just before its first use and waits for it there - ten exposed LDS
+        // latencies per step)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (bi + 1 < 8) ld(std::integral_constant<int, bi + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          if constexpr (DP_ROWS_EXP & 4) { acc[A_OLD][pt][0] += __builtin_bit_cast(float, bf[bi & 1][kx][0]); }
+          else {
+            Mma<T>::run(wfr[cb * 9 + 6 + kx], bf[bi & 1][kx], acc[A_OLD][pt]);
+            Mma<T>::run(wfr[cb * 9 + 3 + kx], bf[bi & 1][kx], acc[A_MID][pt]);
+            Mma<T>::run(wfr[cb * 9 + 0 + kx], bf[bi & 1][kx], acc[A_NEW][pt]);
+          }
+        }
+      });
+      __builtin_amdgcn_s_setprio(0);
+    }
+    // the finished row's partial sums (whatever they are when nothing is emitted: the reduction then stores out of range)
+    *reinterpret_cast<f32x4*>(stg_w + c_par * STGB) = acc[A_OLD][0];
+    *reinterpret_cast<f32x4*>(stg_w + c_par * STGB + 1024) = acc[A_OLD][1];
+  };
+
+  // prologue: rows 0 and 1 staged and visible to the whole workgroup
+  fetch_next();
+  fetch_next();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // Per wave and step, in issue order: 5 LDS-DMA pieces (4 + the masked one), 1 store. The pieces of row s + 1 must have landed
+  // before the barrier that ends the interval in which this wave computes row s: younger than them are the store of that interval,
+  // the pieces of row s + 2 and the store of this one = 7 operations (the masked piece counts: exec = 0 lanes still issue).
+  // Waves 0 .. 3: A (reduction reads, bookkeeping, LDS-DMA issue of row s + 2, sums + store), B | ; waves 4 .. 7: A (without the
+  // LDS-DMA issue) | B, LDS-DMA issue - after every barrier one wave of a SIMD starts with memory work, the other with its matrix
+  // block. Row s + 2 goes to the slot of row s - 1, which its ring's readers (waves of the same half) finished before their last barrier.
+  auto unit = [&](auto ph_c, int s) __attribute__((always_inline)) {
+    DP_STAMP(7)
+    phase_a(s);
+    if (sched_y) {
+      reduce_finish(p2_t, p2_ob, s >= 2 && p2_emit);
+      DP_STAMP(1)
+      asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      DP_STAMP(2)
+      __builtin_amdgcn_s_barrier();
+      DP_STAMP(3)
+    } else {
+      fetch_next();
+      DP_STAMP(4)
+      reduce_finish(p2_t, p2_ob, s >= 2 && p2_emit);
+      DP_STAMP(1)
+    }
+    phase_b(ph_c, s);
+    if constexpr (DP_ROWS_EXP & 16) asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[1][0][0]), "v"(acc[2][0][0]), "v"(acc[0][1][0]), "v"(acc[1][1][0]), "v"(acc[2][1][0]));
+    DP_STAMP(5)
+    if (!sched_y) {
+      asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      DP_STAMP(2)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      DP_STAMP(6)
+      __builtin_amdgcn_s_barrier();
+      DP_STAMP(3)
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      DP_STAMP(6)
+      fetch_next();
+      DP_STAMP(4)
+    }
+  };
+  for (int s = 0; s < n_steps; s += 3) {
+    unit(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < n_steps) unit(std::integral_constant<int, 1>{}, s + 1);
+    if (s + 2 < n_steps) unit(std::integral_constant<int, 2>{}, s + 2);
+  }
+  __builtin_amdgcn_s_barrier();                  // waves 4 .. 7 have written the last step's partial sums
+  {
+    const int tl_ = it_c.q - 1;
+    const int par1 = c_par, par2 = c_par == 0 ? 2 : c_par - 1;
+    if (n_steps >= 2) { reduce_issue(par2); reduce_finish(p1_t, p1_ob, p1_emit); }
+    reduce_issue(par1);
+    reduce_finish(tl_, r_obase, tl_ >= it_c.r_lo);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy fetches behind the last step still target this workgroup's LDS
+  if constexpr (DP_ROWS_EXP & 16) {
+    if (lane == 0 && p.dbg) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p.dbg[(blockIdx.x * 8 + wave) * 16 + k] = ph[k];
+      p.dbg[(blockIdx.x * 8 + wave) * 16 + 8] = n_steps;
+    }
+  }
+#undef DP_STAMP
+}
+
+template <typename T>
+int launch_rows2(const RowsArgs& a, hipStream_t stream) {
+  constexpr int lds = 4 * 3 * 35 * 272 + 3 * 16 * 1024;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_rows2_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+#if DP_ROWS_EXP & 16
+  RowsArgs b = a;
+  static unsigned long long* dbg = nullptr;
+  const int nblk = a.n_pg * a.n_slices;
+  if (!dbg) (void)hipMalloc(&dbg, sizeof(unsigned long long) * 8 * 16 * 4096);
+  b.dbg = dbg;
+  (void)hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 8 * 16 * nblk, stream);
+  hipLaunchKernelGGL((conv3x3_rows2_kernel<T>), dim3(nblk), dim3(512), lds, stream, b);
+  {
+    static int shown = 0;
+    if (shown++ % 40 == 4) {   // a warm launch (and again for every further mode of tools/rows_micro.py)
+      (void)hipStreamSynchronize(stream);
+      unsigned long long* hb = (unsigned long long*)malloc(sizeof(unsigned long long) * 128 * nblk);
+      (void)hipMemcpy(hb, dbg, sizeof(unsigned long long) * 128 * nblk, hipMemcpyDeviceToHost);
+      for (int w = 0; w < 8; ++w) {
+        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n = 0;
+        for (int bb = 0; bb < nblk; ++bb) { for (int k = 0; k < 8; ++k) sum[k] += (double)hb[(bb * 8 + w) * 16 + k]; n += (double)hb[(bb * 8 + w) * 16 + 8]; }
+        fprintf(stderr, "rows2 wave %d (lockstep %d): cycles per step: bookkeeping%s %.0f  reduce %.0f  vmcnt wait %.0f  barrier %.0f  fetch issue after the barrier %.0f  B: reads + mfma + staging write %.0f  lgkm wait %.0f  loop edge %.0f  (steps/wg %.1f)\n",
+                w, a.lockstep, (w < 4 && !a.lockstep) ? " + fetch issue" : "", sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n, sum[6] / n, sum[7] / n, n / nblk);
+      }
+      free(hb);
+    }
+  }
+#else
+  hipLaunchKernelGGL((conv3x3_rows2_kernel<T>), dim3(a.n_pg * a.n_slices), dim3(512), lds, stream, a);
+#endif
+  return dp_check_launch("conv3x3_rows2_kernel");
+}
+
 template <typename T>
 int launch_chain(const RowsArgs& a, hipStream_t stream) {
   constexpr int lds = 8 * 4 * 3072 + 7 * 4 * 2048 + 2 * 2048 + 64;
@@ -697,43 +1060,81 @@ bool rows_width_ok(int W) {
   return true;
 }
 
-}  // namespace
+// every 32-pixel strip of a group of G = 32 / gcd(W, 32) images is at most two segments from two consecutive images, and a group is at
+// most 8 images (a launch works on whole groups: 28-wide ROI maps G = 8; res5's 42-wide maps would need 16 images for 21 strips)
+bool rows2_width_ok(int W) {
+  if (W < 16) return false;
+  const int G = 32 / gcd_i(W, 32), spg = G * W / 32;
+  if (G > 8) return false;
+  for (int k = 0; k < spg; ++k) {
+    const int c00 = (32 * k) % W, len0 = W - c00 < 32 ? W - c00 : 32;
+    if (32 - len0 > W) return false;
+  }
+  return true;
+}
 
-// used by dp_conv2d_nhwc (dp_conv.hip): is this launch a 3x3 / pad 1 / stride 1 layer the kernel is written for? No size thresholds:
-// the kernel's summation order differs from the LDS-ring kernels', so a layer either always runs here or never (batch invariance).
-bool dp_conv_rows_ok(const dp_conv_params* p) {
-  // Default (mode 1): the 512-channel layers on plain tensors - res5's conv2, 45 us against 60 - 64 on the LDS-ring kernels at batch 8.
-  // Launches sized on the device (n_dev: the DensePose head on R x 28 x 28 ROI maps) stay on the ring kernel: measured at par there
-  // (profiles/r4_rows_kernel_experiments.txt), and which kernel a call site takes must not depend on the batch - n_dev is a property
-  // of the call site. A/B knob DP_CONV_ROWS: 0 never, 2 also the n_dev launches and the 256 -> 512 layer.
-  const char* e = getenv("DP_CONV_ROWS");
-  const int mode = e ? atoi(e) : 1;
-  if (mode == 0 || (mode != 2 && p->n_dev != nullptr)) return false;
-  const bool shape = (p->Cin == 512 && p->Cout % 32 == 0) || (p->Cin == 256 && p->Cout % 64 == 0 && mode == 2);
-  const int g = 16 / gcd_i(p->W > 0 ? p->W : 16, 16);
-  return (p->dtype == DP_BF16 || p->dtype == DP_F16) && shape && p->ntaps == 9 && p->Kpad == 9 * p->Cin && p->stride == 1 &&
-         (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == -1 && p->wi_off == -1 && p->H == p->Ho && p->W == p->Wo && rows_width_ok(p->W) &&
+bool rows_common_ok(const dp_conv_params* p, int g) {
+  return (p->dtype == DP_BF16 || p->dtype == DP_F16) && p->ntaps == 9 && p->Kpad == 9 * p->Cin && p->stride == 1 &&
+         (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == -1 && p->wi_off == -1 && p->H == p->Ho && p->W == p->Wo &&
          !p->residual && !p->out_f32 && !p->head_out && !p->in2 && !p->post_res && p->post_mode == 0 && p->split_k <= 1 && p->out &&
          p->osW >= p->Cout && p->osW % 8 == 0 && p->osH == (long long)p->W * p->osW && p->osN == (long long)p->H * p->W * p->osW &&
          p->Cout <= p->Cout_w && p->Cout_w % 64 == 0 &&
          (long long)(p->N + g) * p->H * p->W * p->Cin * 2 < (1ll << 31) && (long long)(p->N + g) * p->H * p->W * p->osW * 2 < (1ll << 31);
 }
 
+// the 32-pixel form: 512 input channels and a width whose strip groups are small (decided by the geometry alone: its summation order
+// differs from the 16-pixel form's). A/B knob DP_CONV_ROWS2=0.
+bool rows2_ok(const dp_conv_params* p) {
+  const char* e = getenv("DP_CONV_ROWS2");
+  const char* e1 = getenv("DP_CONV_ROWS");
+  if ((e && atoi(e) == 0) || (e1 && atoi(e1) == 0)) return false;
+  return p->Cin == 512 && p->Cout % 32 == 0 && p->W > 0 && rows2_width_ok(p->W) && rows_common_ok(p, 32 / gcd_i(p->W, 32));
+}
+
+}  // namespace
+
+// used by dp_conv2d_nhwc (dp_conv.hip): is this launch a 3x3 / pad 1 / stride 1 layer the kernels here are written for? No size
+// thresholds: their summation orders differ from the LDS-ring kernels' (and from each other), so a layer either always runs on one form
+// or never (batch invariance).
+bool dp_conv_rows_ok(const dp_conv_params* p) {
+  // Default (mode 1): the 512-channel layers. Widths with small 32-pixel strip groups (the DensePose head's 28-wide ROI maps, with or
+  // without a device-side count) take the 32-pixel form; the others (res5's conv2 at 42 columns) the 16-pixel form when the launch is
+  // not sized on the device - for n_dev launches the 16-pixel form measured at par with the ring kernel
+  // (profiles/r4_rows_kernel_experiments.txt), and which kernel a call site takes must not depend on the batch. A/B knob DP_CONV_ROWS:
+  // 0 never, 2 the 16-pixel form also for n_dev launches and the 256 -> 512 layer.
+  const char* e = getenv("DP_CONV_ROWS");
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 0) return false;
+  if (mode != 2 && p->n_dev != nullptr) return false;
+  const bool shape = (p->Cin == 512 && p->Cout % 32 == 0) || (p->Cin == 256 && p->Cout % 64 == 0 && mode == 2);
+  return shape && p->W > 0 && rows_width_ok(p->W) && rows_common_ok(p, 16 / gcd_i(p->W, 16));
+}
+
+bool dp_conv_rows2_ok(const dp_conv_params* p) { return rows2_ok(p); }
+
 int dp_conv_rows_launch(const dp_conv_params* p, dp_stream_t stream) {
   RowsArgs a;
   a.in = p->in; a.w = p->weight; a.bias = p->bias; a.out = p->out; a.n_dev = p->n_dev;
   a.N = p->N; a.H = p->H; a.W = p->W; a.relu = p->relu; a.opitch = (int)p->osW; a.kpad = p->Kpad;
-  a.G = 16 / gcd_i(p->W, 16);
-  a.SPG = a.G * p->W / 16;
+  const bool two = rows2_ok(p);
+  const int sw = two ? 32 : 16;
+  a.G = sw / gcd_i(p->W, sw);
+  a.SPG = a.G * p->W / sw;
   const int nc = p->Cin == 512 ? 32 : 64;
   a.n_slices = p->Cout / nc;
   int groups = rows_num_cus() / (8 * a.n_slices);
   if (groups < 1) groups = 1;
   a.n_pg = groups * 8;
   a.dbg = nullptr;
+  a.lockstep = 0;
   a.in_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cin * 2);
   a.out_bytes = (unsigned)((long long)p->N * p->H * p->W * p->osW * 2);
   hipStream_t s = as_stream(stream);
+  if (two) {
+    const char* le = getenv("DP_CONV_ROWS2_LOCKSTEP");     // A/B knob: 1 = all eight waves on one schedule
+    a.lockstep = le && atoi(le) == 1;
+    return p->dtype == DP_BF16 ? launch_rows2<uint16_t>(a, s) : launch_rows2<f16_t>(a, s);
+  }
   const char* ce = getenv("DP_CONV_ROWS_CHAIN");     // A/B knob: 1 = the barrier-free chain form for the 512-channel layers
   if (p->Cin == 512 && ce && atoi(ce) == 1) return p->dtype == DP_BF16 ? launch_chain<uint16_t>(a, s) : launch_chain<f16_t>(a, s);
   return p->dtype == DP_BF16 ? launch_rows<uint16_t>(a, p->Cin, s) : launch_rows<f16_t>(a, p->Cin, s);

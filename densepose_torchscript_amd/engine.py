@@ -258,7 +258,7 @@ class Engine:
             e0.record(torch.cuda.current_stream(self.device))
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
             e1.record(torch.cuda.current_stream(self.device))
-            cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_ring_kernel<256x256>", "conv_ring_kernel<128x128>", "conv_ring2_kernel<256x128>", "conv1x1_stream_kernel", "conv3x3_wsr_kernel", "conv3x3_rows_kernel")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
+            cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_ring_kernel<256x256>", "conv_ring_kernel<128x128>", "conv_ring2_kernel<256x128>", "conv1x1_stream_kernel", "conv3x3_wsr_kernel", "conv3x3_rows_kernel", "conv3x3_rows2_kernel")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
             if cls.startswith("conv_ring_kernel<"):   # one template instance (= one rocprofv3 kernel name) per tile height
                 cls = "conv_ring_kernel<%dx%s" % (self.lib.dp_conv2d_tile_rows(C.byref(p)), cls.split("x")[1])
                 if in2 is not None:                   # ... and per source count (the two-source form is its own instance)

@@ -119,7 +119,7 @@ typedef struct {
    * skipped (N keeps sizing the launch and the tensors). The DensePose head runs on R detected boxes (roi_head.py:126-158); R is
    * known on the device only - sizing its launches on the host costs a device -> host round trip in the middle of every step.
    * Rows behind *n_dev inside the last live tile are computed on whatever the input holds: every image (ROI) is independent,
-   * their outputs are never read. Honoured by the tiled kernels (classes 0 - 4) and class 7; a launch with n_dev is never given to
+   * their outputs are never read. Honoured by the tiled kernels (classes 0 - 4) and classes 7 / 8; a launch with n_dev is never given to
    * the persistent kernels that ignore it (classes 5 and 6: they would do the full work on all N images). */
   const int32_t* n_dev;
   /* Second source of a pointwise (1 tap, stride 1) layer: K = Cin channels of `in` followed by Cin2 channels of `in2`, an
@@ -146,7 +146,9 @@ int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
  * (128 -> 128 / 256 -> 256 channels, weights in registers), 7 = row-streaming K-split weight-stationary 3x3 (512 input channels, or
  * 256 -> 512: the DensePose head v1convx.py:44-59 / deeplab.py:64-74 and res5's conv2 resnet.py:195-197; it honours n_dev by sizing
  * its work from the live image count, and its per-pixel summation order - fixed, but not the other kernels' - is why a layer it
- * takes runs on it for EVERY batch size) - profiling / roofline bookkeeping only */
+ * takes runs on it for EVERY batch size), 8 = the same with 32 pixels per step and the waves split 4 K quarters x 2 cout halves (512
+ * input channels on maps whose width gives strip groups of at most 8 images, e.g. the DensePose head's 28-wide ROI maps, with or
+ * without n_dev; chosen by the geometry alone, its summation order differs from class 7's) - profiling / roofline bookkeeping only */
 int dp_conv2d_kernel_class(const dp_conv_params* p);
 /* pixel rows of the tile dp_conv2d_nhwc will use for these parameters (the 256-cout ring kernel picks 128 .. 256 rows in
  * steps of 32 to fit the launch into whole rounds of the chip) - profiling / roofline bookkeeping only */

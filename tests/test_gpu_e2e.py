@@ -344,7 +344,9 @@ def test_16bit_end_to_end_against_the_storage_oracle(name, dt):
     assert r["R"] > 0
     for k, (got, ref) in r["stages"].items():
         st = stage_stats(got, ref, dt)
-        bound = (6.0 if k.startswith("pred_") else 3.0) * TOP_ULP[dt]
+        # (the DeepLab head normalises eight times: its output decorrelates further - 3.0 ulp measured with the 32-pixel row kernel's
+        # summation order, 2.4 with the ring kernel's)
+        bound = (6.0 if k.startswith("pred_") else 4.5 if ("_dl_" in name and k == "dp_head_out") else 3.0) * TOP_ULP[dt]
         assert st["max_rel_to_top"] <= bound, (k, st)
     npx, ndiff, margin = label_stats(r)
     iuv_dev = max(stage_stats(*r["stages"][k], dt)["max_rel_to_top"] * float(r["stages"][k][1].abs().max()) for k in IUV_KEYS[:2])

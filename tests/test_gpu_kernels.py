@@ -509,10 +509,32 @@ ROWS_CASES = [
     (512, 96, 3, 5, 17, None, True),        # three cout slices only: more workgroups than rows
     (256, 512, 2, 37, 48, None, True),
     (512, 512, 70, 28, 28, 64, True),       # the benchmark's 64 ROIs inside a larger slot count
+    (512, 512, 9, 28, 28, None, True),      # a ragged group of the 32-pixel form (groups of eight ROIs)
+    (512, 96, 5, 25, 40, None, True),       # 40 columns: groups of four images, strips of 32 + (8 | 24), (16 | 16), ...
+    (512, 512, 3, 9, 56, 2, False),
+    (512, 160, 2, 30, 32, None, True),      # whole strips only
+    (512, 512, 5, 7, 24, None, True),
 ]
 
 
-@pytest.mark.parametrize("variant", ["rows", "chain"])     # chain: the barrier-free form of the 512-channel kernel (DP_CONV_ROWS_CHAIN=1, an A/B knob)
+def _rows2_width_ok(W):
+    """mirror of rows2_width_ok (dp_conv_rows.hip): groups of at most 8 images, every 32-pixel strip at most two segments"""
+    import math
+    if W < 16:
+        return False
+    G = 32 // math.gcd(W, 32)
+    if G > 8:
+        return False
+    for k in range(G * W // 32):
+        c00 = (32 * k) % W
+        if 32 - min(W - c00, 32) > W:
+            return False
+    return True
+
+
+# rows: the 16-pixel form; chain: its barrier-free variant (DP_CONV_ROWS_CHAIN=1, an A/B knob); rows2: the 32-pixel form (4 K quarters x
+# 2 cout halves) that the default policy picks where the width allows; rows2_lockstep: the same on one schedule for all waves (A/B knob)
+@pytest.mark.parametrize("variant", ["rows", "chain", "rows2", "rows2_lockstep"])
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", ROWS_CASES)
 def test_conv3x3_rows_kernel(eng, dt, case, variant, monkeypatch):
@@ -526,13 +548,22 @@ def test_conv3x3_rows_kernel(eng, dt, case, variant, monkeypatch):
     from densepose_torchscript_amd.pack import conv_from_oihw
     e = eng[dt]
     Ci, Co, N, H, W, live, relu = case
+    two_ok = Ci == 512 and _rows2_width_ok(W)
+    monkeypatch.delenv("DP_CONV_ROWS_CHAIN", raising=False)
+    monkeypatch.delenv("DP_CONV_ROWS2_LOCKSTEP", raising=False)
     if variant == "chain":
         if Ci != 512:
             pytest.skip("the chain form exists for 512 input channels")
         monkeypatch.setenv("DP_CONV_ROWS_CHAIN", "1")
+    if variant.startswith("rows2"):
+        if not two_ok:
+            pytest.skip("the 32-pixel form takes 512 input channels and widths with strip groups of at most 8 images")
+        monkeypatch.delenv("DP_CONV_ROWS2", raising=False)
+        if variant == "rows2_lockstep":
+            monkeypatch.setenv("DP_CONV_ROWS2_LOCKSTEP", "1")
     else:
-        monkeypatch.delenv("DP_CONV_ROWS_CHAIN", raising=False)
-    monkeypatch.setenv("DP_CONV_ROWS", "2")     # every shape the kernel takes (default policy: 512 input channels, no device-side count)
+        monkeypatch.setenv("DP_CONV_ROWS2", "0")
+    monkeypatch.setenv("DP_CONV_ROWS", "2")     # every shape the kernels take
     g = torch.Generator().manual_seed(Ci + Co + N * 1000 + H * 10 + W)
     x = _round(torch.randn((N, Ci, H, W), generator=g), dt)
     w = _round(torch.randn((Co, Ci, 3, 3), generator=g) * (1.0 / (9 * Ci)) ** 0.5, dt)
@@ -544,13 +575,17 @@ def test_conv3x3_rows_kernel(eng, dt, case, variant, monkeypatch):
     p.stride, p.ntaps, p.dtype, p.hi_off, p.wi_off = 1, 9, e.dt, -1, -1
     p.osN, p.osH, p.osW = H * W * Co, W * Co, Co
     p.out = 1
-    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 7
+    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == (8 if variant.startswith("rows2") else 7)
     n_dev = None if live is None else torch.tensor([live], dtype=torch.int32, device=e.device)
-    # the default policy: a call site is on this kernel for every batch or for none - 512-channel layers on plain tensors (res5's conv2)
-    # are, launches sized on the device (the DensePose head) and the 256 -> 512 layer are not
+    # the default policy: a call site is on this kernel class for every batch or for none - 512-channel layers whose width suits the
+    # 32-pixel form always (the DensePose head's ROI maps, sized on the device or not), other 512-channel layers on plain tensors
+    # (res5's conv2) on the 16-pixel form; the 256 -> 512 layer and device-sized launches of other widths are not
     monkeypatch.delenv("DP_CONV_ROWS")
     p.n_dev = None if n_dev is None else n_dev.data_ptr()
-    assert (e.lib.dp_conv2d_kernel_class(C.byref(p)) == 7) == (Ci == 512 and live is None)
+    if variant.startswith("rows2"):
+        assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 8
+    else:
+        assert (e.lib.dp_conv2d_kernel_class(C.byref(p)) == 7) == (Ci == 512 and live is None)
     p.n_dev = None
     monkeypatch.setenv("DP_CONV_ROWS", "2")
     nl = N if live is None else live
@@ -569,7 +604,7 @@ def test_conv3x3_rows_kernel(eng, dt, case, variant, monkeypatch):
         assert torch.equal(one.t[0], got.t[i]), i
     # the ring kernels on the same operands: equal up to the summation order
     monkeypatch.setenv("DP_CONV_ROWS", "0")
-    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) != 7
+    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) not in (7, 8)
     want = e.conv(layer, xa, relu=relu)
     torch.cuda.synchronize()
     d = (want.t[:nl].float() - got.t[:nl].float()).abs()

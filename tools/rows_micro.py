@@ -1,5 +1,5 @@
 """One DensePose-head layer (3x3, 512 -> 512 on R x 28 x 28 ROI maps) in a loop: the row-streaming kernel (class 7) against the LDS-ring
-kernel (DP_CONV_ROWS=0), HIP-event time per launch.  usage: rows_micro.py [R] [Cin] [H] [W] [dtype]"""
+kernel, HIP-event time per launch.  usage: [MODES=rows32,rows16,ring,chain,rows32-lockstep] [COUT=512] rows_micro.py [R] [Cin] [H] [W] [dtype]"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from densepose_torchscript_amd import TINY_OPTS, get_config, make_synthetic_state
@@ -19,14 +19,31 @@ w = (torch.randn((Co, Ci, 3, 3), generator=g) * (1.0 / (9 * Ci)) ** 0.5)
 layer = conv_from_oihw("fcn", w.numpy(), torch.zeros(Co).numpy(), Ci, 1, 1, 1, e.dt, e.device)
 xa = Act(x, R, H, W, Ci)
 flops = 2.0 * R * H * W * Co * Ci * 9
-def run(n=30):
-    for _ in range(5): e.conv(layer, xa, relu=True)
+def run(n=100):
+    for _ in range(10): e.conv(layer, xa, relu=True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): e.conv(layer, xa, relu=True)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for mode in (os.environ.get("ROWS_ON", "1"), "0") * 2:
-    os.environ["DP_CONV_ROWS"] = mode
-    ms = run()
-    print("R=%d %dx%d %d->%d %s DP_CONV_ROWS=%s: %.1f us  %.0f TFLOP/s (%.3f of 2.5 PF)" % (R, H, W, Ci, Co, dt, mode, ms * 1e3, flops / ms / 1e9, flops / ms / 1e9 / 2500))
+MODES = {"ring": {"DP_CONV_ROWS": "0"}, "rows16": {"DP_CONV_ROWS": "2", "DP_CONV_ROWS2": "0"}, "rows32": {"DP_CONV_ROWS": "2", "DP_CONV_ROWS2": "1"},
+         "rows32-lockstep": {"DP_CONV_ROWS": "2", "DP_CONV_ROWS2": "1", "DP_CONV_ROWS2_LOCKSTEP": "1"}, "chain": {"DP_CONV_ROWS": "2", "DP_CONV_ROWS2": "0", "DP_CONV_ROWS_CHAIN": "1"}}
+names = os.environ.get("MODES", "rows32,rows32-lockstep,rows16,ring").split(",")
+def setmode(name):
+    for k in ("DP_CONV_ROWS", "DP_CONV_ROWS2", "DP_CONV_ROWS2_LOCKSTEP", "DP_CONV_ROWS_CHAIN"):
+        os.environ.pop(k, None)
+    os.environ.update(MODES[name])
+# the chip's clock settles over hundreds of milliseconds: 1.5 s of the same load first, then the modes in turn, three passes
+setmode(names[0])
+import time
+t0 = time.time()
+while time.time() - t0 < 1.5:
+    run(50)
+res = {n: [] for n in names}
+for _ in range(3):
+    for name in names:
+        setmode(name)
+        res[name].append(run())
+for name in names:
+    ms = sorted(res[name])[1]
+    print("R=%d %dx%d %d->%d %s %-16s median %.1f us (%s)  %.0f TFLOP/s (%.3f of 2.5 PF)" % (R, H, W, Ci, Co, dt, name, ms * 1e3, " ".join("%.1f" % (x * 1e3) for x in res[name]), flops / ms / 1e9, flops / ms / 1e9 / 2500))
