@@ -377,7 +377,8 @@ def main():
     for tname in sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json"))), reverse=True):   # newest committed PMC summary that has this kernel
         tpath = os.path.join(ROOT, "profiles", tname)
         if traffic is None and os.path.exists(tpath) and args.dtype == "bf16" and args.config == "densepose_rcnn_R_50_FPN_s1x" and args.batch == 8:
-            k = json.load(open(tpath))["kernels"].get(dom + "[bf16]")
+            ks = json.load(open(tpath))["kernels"]
+            k = ks.get(dom + "[bf16]") or ks.get(dom)      # (tools/pmc_summary.py tags the multi-dtype template families only)
             if k:
                 traffic = {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "measured_in_this_run": False,
                            "source": "from committed profile: profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % tname}

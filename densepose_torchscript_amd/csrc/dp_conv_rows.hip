@@ -28,6 +28,10 @@
 #include "dp_mma.h"
 #include <stdlib.h>
 
+#ifndef DP_ROWS2_OPT
+#define DP_ROWS2_OPT 0    // experiments on conv3x3_rows2_kernel (results stay exact): 1 fragment reads two batches ahead, 2 no s_setprio, 4 waves 4 .. 7 issue their
+                          // LDS-DMA pieces in the middle of the matrix block, 8 waves 0 .. 3 store the reduced row before they issue their pieces
+#endif
 #ifndef DP_ROWS_EXP
 #define DP_ROWS_EXP 0     // diagnostic builds (timing only, results garbage): 1 no LDS-DMA in the loop, 2 no reduction, 4 no MFMAs, 8 no fragment reads,
                           // 16 in-kernel phase stamps (s_memtime sums per wave, printed by the fifth launch)
@@ -837,7 +841,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
     }
     DP_STAMP(0)
   };
-  u32x4 bf[2][3];
+  constexpr int NBUF = (DP_ROWS2_OPT & 1) ? 3 : 2;
+  u32x4 bf[NBUF][3];
   auto phase_b = [&](auto ph_c, int s) __attribute__((always_inline)) {
     constexpr int PH = decltype(ph_c)::value;
     constexpr int A_OLD = (PH + 2) % 3, A_MID = PH, A_NEW = (PH + 1) % 3;
@@ -853,30 +858,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
         const unsigned char* const r = pt ? row1 : row0;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          if constexpr (DP_ROWS_EXP & 8) bf[bi & 1][kx] = u32x4{(unsigned)lane, (unsigned)bi, 1u, 2u};
-          else bf[bi & 1][kx] = *reinterpret_cast<const u32x4*>(r + kx * PPW + cb * 64);
+          if constexpr (DP_ROWS_EXP & 8) bf[bi % NBUF][kx] = u32x4{(unsigned)lane, (unsigned)bi, 1u, 2u};
+          else bf[bi % NBUF][kx] = *reinterpret_cast<const u32x4*>(r + kx * PPW + cb * 64);
         }
       };
       ld(std::integral_constant<int, 0>{});
-      __builtin_amdgcn_s_setprio(1);
+      if constexpr (NBUF == 3) ld(std::integral_constant<int, 1>{});
+      if constexpr (!(DP_ROWS2_OPT & 2)) __builtin_amdgcn_s_setprio(1);
       static_for<0, 8>([&](auto bb) {
         constexpr int bi = decltype(bb)::value, pt = bi >> 2, cb = bi & 3;
         // (fenced: left alone hipcc moves each read down to just before its first use and waits for it there - ten exposed LDS
         // latencies per step)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (bi + 1 < 8) ld(std::integral_constant<int, bi + 1>{});
+        if constexpr (bi + NBUF - 1 < 8) ld(std::integral_constant<int, bi + NBUF - 1>{});
+        if constexpr ((DP_ROWS2_OPT & 4) != 0 && bi == 4) { if (sched_y) fetch_next(); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          if constexpr (DP_ROWS_EXP & 4) { acc[A_OLD][pt][0] += __builtin_bit_cast(float, bf[bi & 1][kx][0]); }
+          if constexpr (DP_ROWS_EXP & 4) { acc[A_OLD][pt][0] += __builtin_bit_cast(float, bf[bi % NBUF][kx][0]); }
           else {
-            Mma<T>::run(wfr[cb * 9 + 6 + kx], bf[bi & 1][kx], acc[A_OLD][pt]);
-            Mma<T>::run(wfr[cb * 9 + 3 + kx], bf[bi & 1][kx], acc[A_MID][pt]);
-            Mma<T>::run(wfr[cb * 9 + 0 + kx], bf[bi & 1][kx], acc[A_NEW][pt]);
+            Mma<T>::run(wfr[cb * 9 + 6 + kx], bf[bi % NBUF][kx], acc[A_OLD][pt]);
+            Mma<T>::run(wfr[cb * 9 + 3 + kx], bf[bi % NBUF][kx], acc[A_MID][pt]);
+            Mma<T>::run(wfr[cb * 9 + 0 + kx], bf[bi % NBUF][kx], acc[A_NEW][pt]);
           }
         }
       });
-      __builtin_amdgcn_s_setprio(0);
+      if constexpr (!(DP_ROWS2_OPT & 2)) __builtin_amdgcn_s_setprio(0);
+    } else if constexpr ((DP_ROWS2_OPT & 4) != 0) {
+      if (sched_y) fetch_next();
     }
     // the finished row's partial sums (whatever they are when nothing is emitted: the reduction then stores out of range)
     *reinterpret_cast<f32x4*>(stg_w + c_par * STGB) = acc[A_OLD][0];
@@ -905,6 +914,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
       DP_STAMP(2)
       __builtin_amdgcn_s_barrier();
       DP_STAMP(3)
+    } else if constexpr ((DP_ROWS2_OPT & 8) != 0) {
+      reduce_finish(p2_t, p2_ob, s >= 2 && p2_emit);
+      DP_STAMP(1)
+      fetch_next();
+      DP_STAMP(4)
     } else {
       fetch_next();
       DP_STAMP(4)
@@ -915,7 +929,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
     if constexpr (DP_ROWS_EXP & 16) asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[1][0][0]), "v"(acc[2][0][0]), "v"(acc[0][1][0]), "v"(acc[1][1][0]), "v"(acc[2][1][0]));
     DP_STAMP(5)
     if (!sched_y) {
-      asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      if constexpr ((DP_ROWS2_OPT & 8) != 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // store, then the pieces: one operation fewer behind row s + 1
+      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       DP_STAMP(2)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       DP_STAMP(6)
@@ -924,7 +939,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
     } else {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       DP_STAMP(6)
-      fetch_next();
+      if constexpr (!(DP_ROWS2_OPT & 4)) fetch_next();
       DP_STAMP(4)
     }
   };
