@@ -106,7 +106,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const RowsArgs p) 
   const int pg = (b & 7) + 8 * (b / (8 * p.n_slices));
 
   const int n_live = p.n_dev ? min(*p.n_dev, p.N) : p.N;
-  const int n_strips = ((n_live + p.G - 1) / p.G) * p.SPG;
+  // whole groups of G images, then the strips that the columns of the remaining images reach (a strip is SW = G * W / SPG pixels)
+  const int n_strips = (n_live / p.G) * p.SPG + ((n_live % p.G) * p.W * p.SPG + p.G * p.W - 1) / (p.G * p.W);
   const long long TR = (long long)n_strips * p.H;
   const int wa = (int)(TR * pg / p.n_pg), wb = (int)(TR * (pg + 1) / p.n_pg);
   if (wb <= wa) return;
@@ -419,7 +420,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_chain_kernel(const RowsArgs p)
   const int pg = (b & 7) + 8 * (b / (8 * p.n_slices));
 
   const int n_live = p.n_dev ? min(*p.n_dev, p.N) : p.N;
-  const int n_strips = ((n_live + p.G - 1) / p.G) * p.SPG;
+  // whole groups of G images, then the strips that the columns of the remaining images reach (a strip is SW = G * W / SPG pixels)
+  const int n_strips = (n_live / p.G) * p.SPG + ((n_live % p.G) * p.W * p.SPG + p.G * p.W - 1) / (p.G * p.W);
   const long long TR = (long long)n_strips * p.H;
   const int wa = (int)(TR * pg / p.n_pg), wb = (int)(TR * (pg + 1) / p.n_pg);
   if (wb <= wa) return;
@@ -650,15 +652,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_chain_kernel(const RowsArgs p)
 // are added in quarter order. Fixed, independent of strip, lane, workgroup and batch - and different from the two forms above and from
 // the LDS-ring kernels: which form a layer takes is decided by its geometry alone (dp_conv_rows_launch).
 // =====================================================================================================
-template <typename T>
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+template <int N>
+__device__ __forceinline__ void rows2_wait_vm() {
+  static_assert(N >= 4 && N <= 7, "vmcnt immediate");
+  if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+}
+
+template <typename T, int CIN>
 __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
-  constexpr int CIN = 512, KPQ = 128, NCB = 4, PPW = KPQ * 2 + 16, NPX = 35;
-  constexpr int ROWB = NPX * PPW;               // 9520 bytes: nine whole 1 KiB pieces and 19 lanes of a tenth
-  constexpr int NPW = 5;                        // pieces per wave and row (wave ch = 0: pieces 0 .. 4, ch = 1: 5 .. 9)
-  constexpr int D = 2, NSLOT = 3;
+  static_assert(CIN == 512 || CIN == 256, "36 weight fragments per wave");
+  constexpr int KPQ = CIN / 4;                  // input channels of a K quarter
+  constexpr int NCB = KPQ / 32;                 // 32-channel blocks per quarter
+  constexpr int NW = 4 / NCB;                   // cout tiles per wave: 1 (512 channels: 32 couts per workgroup) or 2 (256: 64 couts)
+  constexpr int PPW = KPQ * 2 + 16, NPX = 35;   // pixel pitch 272 / 144 bytes: 17 / 9 sixteen-byte slots, odd - conflict-free ds_read_b128
+  constexpr int ROWB = NPX * PPW;               // 9520 / 5040 bytes per staged row slice
+  constexpr int WOFF = ((ROWB / 2 + 511) / 512) * 512;      // wave ch = 0 stages bytes [0, WOFF), ch = 1 [WOFF, ROWB): 5120 / 2560
+  constexpr int NPW = (WOFF + 1023) / 1024;     // pieces per wave and row (5 / 3; the last one of a wave may be narrower than 64 lanes)
+  constexpr int NSLOT = 3;
   constexpr int RING = 4 * NSLOT * ROWB;
-  constexpr int STGB = 16 * 1024;               // staging bytes per parity: [kq][ch][pixel tile][lane] x 16 B
+  constexpr int STGB = 8 * NW * 2 * 1024;       // staging bytes per parity: [kq][ch][cout tile][pixel tile][lane] x 16 B
   constexpr int OOB = (int)0x80000000;
   static_assert(ROWB % 16 == 0 && RING + 3 * STGB <= 160 * 1024, "LDS budget");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -673,23 +691,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
   const int pg = (b & 7) + 8 * (b / (8 * p.n_slices));
 
   const int n_live = p.n_dev ? min(*p.n_dev, p.N) : p.N;
-  const int n_strips = ((n_live + p.G - 1) / p.G) * p.SPG;
+  // whole groups of G images, then the strips that the columns of the remaining images reach (a strip is SW = G * W / SPG pixels)
+  const int n_strips = (n_live / p.G) * p.SPG + ((n_live % p.G) * p.W * p.SPG + p.G * p.W - 1) / (p.G * p.W);
   const long long TR = (long long)n_strips * p.H;
   const int wa = (int)(TR * pg / p.n_pg), wb = (int)(TR * (pg + 1) / p.n_pg);
   if (wb <= wa) return;
 
   // ---- this wave's weights: cout tile ch of the slice x 4 channel blocks of quarter kq x 9 taps
-  u32x4 wfr[NCB * 9];
+  u32x4 wfr[NW * NCB * 9];
+  const int cout0 = slice * (32 * NW);
   {
     const int n_planes = p.kpad * 2 / 64;
     const unsigned char* __restrict__ wp = reinterpret_cast<const unsigned char*>(p.w);
 #pragma unroll
-    for (int cbl = 0; cbl < NCB; ++cbl)
+    for (int ct = 0; ct < NW; ++ct)
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
-        wfr[cbl * 9 + t] = *reinterpret_cast<const u32x4*>(wp + dp_wtile_off(slice * 32 + ch * 16 + fr, (kq * NCB + cbl) * 9 + t, fq, n_planes));
+      for (int cbl = 0; cbl < NCB; ++cbl)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+          wfr[(ct * NCB + cbl) * 9 + t] =
+              *reinterpret_cast<const u32x4*>(wp + dp_wtile_off(cout0 + (ch * NW + ct) * 16 + fr, (kq * NCB + cbl) * 9 + t, fq, n_planes));
   }
-  const int cout0 = slice * 32;
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
   const int in_row = p.W * CIN * 2, out_row = p.W * p.opitch * 2;
@@ -703,14 +725,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
   };
 
   // ---- fetch side: this lane's part of the wave's five pieces of a row slice
+  static_assert(NPW <= 5, "f_boff");
   int f_boff[5];
-  const bool f_last = (ch * NPW + NPW - 1) * 1024 + lane * 16 < ROWB;       // the row's tenth piece is 19 lanes wide
+  const bool f_last = ch * WOFF + (NPW - 1) * 1024 + lane * 16 < (ch ? ROWB : WOFF);       // a wave's last piece may be narrower
   auto setup_fetch = [&](int strip) __attribute__((always_inline)) {
     int img0, c00, len0;
     decode(strip, img0, c00, len0);
 #pragma unroll
     for (int pc = 0; pc < NPW; ++pc) {
-      const int o = (ch * NPW + pc) * 1024 + lane * 16;
+      const int o = ch * WOFF + pc * 1024 + lane * 16;
       const int j = o / PPW, wbyte = o - j * PPW;
       const bool seg1 = j >= len0 + 2;
       const int col = seg1 ? j - (len0 + 2) : c00 - 1 + j;
@@ -720,17 +743,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
     }
   };
   unsigned char* const ring_q = smem + kq * (NSLOT * ROWB);
-  unsigned char* const ring_wv = ring_q + ch * (NPW * 1024);
+  unsigned char* const ring_wv = ring_q + ch * WOFF;
 
   // ---- compute side: lane (fr, fq) = output pixels fr and 16 + fr of the strip
-  // ---- reduce side: wave w adds up the four partial sums of pixel tile w >> 2: lane l takes TWO consecutive output channels of pixel
-  // (l & 31) >> 1 in cout half (w & 1), channel quad 2 * ((w >> 1) & 1) + (l >> 5)
+  // ---- reduce side: wave w adds up the four partial sums of pixel tile w >> 2 in cout half (w & 1).
+  // One cout tile per wave (512 channels): lane l takes TWO consecutive output channels of pixel (l & 31) >> 1, channel quad
+  // 2 * ((w >> 1) & 1) + (l >> 5). Two cout tiles (256 channels): lane l takes FOUR consecutive channels (one lane's values of one
+  // cout tile) of pixel l & 15, channel quad 2 * ((w >> 1) & 1) + ((l >> 4) & 1), cout tile l >> 5.
   const int r_pt = wave >> 2, r_ch = wave & 1;
-  const int r_px = (lane & 31) >> 1, r_fq = 2 * ((wave >> 1) & 1) + (lane >> 5), r_half = lane & 1;
-  const int r_lds = (r_ch * 2 + r_pt) * 1024 + (r_fq * 16 + r_px) * 16 + r_half * 8;
-  float r_bias[2];
-  r_bias[0] = p.bias[cout0 + r_fq * 8 + r_ch * 4 + r_half * 2];
-  r_bias[1] = p.bias[cout0 + r_fq * 8 + r_ch * 4 + r_half * 2 + 1];
+  const int r_px = NW == 1 ? (lane & 31) >> 1 : lane & 15;
+  const int r_fq = 2 * ((wave >> 1) & 1) + (NW == 1 ? lane >> 5 : (lane >> 4) & 1);
+  const int r_half = lane & 1, r_ct = NW == 1 ? 0 : lane >> 5;
+  const int r_lds = ((r_ch * NW + r_ct) * 2 + r_pt) * 1024 + (r_fq * 16 + r_px) * 16 + (NW == 1 ? r_half * 8 : 0);
+  const int r_co = NW == 1 ? r_fq * 8 + r_ch * 4 + r_half * 2 : r_ch * 32 + r_fq * 8 + r_ct * 4;       // first output channel of the lane, in the slice
+  constexpr int RN = NW == 1 ? 2 : 4;           // output channels per lane
+  float r_bias[RN];
+#pragma unroll
+  for (int i = 0; i < RN; ++i) r_bias[i] = p.bias[cout0 + r_co + i];
   int c_frag[2] = {0, 0};
   int r_obase = OOB;
   auto setup_comp = [&](int strip) __attribute__((always_inline)) {
@@ -744,7 +773,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
     const int px = r_pt * 16 + r_px;
     const bool in1 = px >= len0;
     const int img = img0 + (in1 ? 1 : 0), col = in1 ? px - len0 : c00 + px;
-    r_obase = img < n_live ? ((img * p.H * p.W + col) * p.opitch + cout0 + r_fq * 8 + r_ch * 4 + r_half * 2) * 2 : OOB;
+    r_obase = img < n_live ? ((img * p.H * p.W + col) * p.opitch + cout0 + r_co) * 2 : OOB;
   };
 
   auto seg_init = [&](RowsIt& it, int strip) __attribute__((always_inline)) {
@@ -783,35 +812,43 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
     }
   };
 
-  f32x4 acc[3][2];
+  f32x4 acc[3][NW][2];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) acc[a][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < NW; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) acc[a][ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   unsigned char* const stg = smem + RING;
-  unsigned char* const stg_w = stg + ((kq * 2 + ch) * 2) * 1024 + lane * 16;
+  unsigned char* const stg_w = stg + ((kq * 2 + ch) * NW * 2) * 1024 + lane * 16;
 
   // the row step s finished: four partial tiles in staging parity s % 3 -> bias, activation, one 4-byte store per lane. ALWAYS one
   // store per step (out of range when there is nothing to store: the hardware drops it) - the counted vmcnt waits below rely on it.
   // In two halves: the four LDS reads are issued at the top of phase A, the sums are taken after the step's LDS-DMA issue.
-  f32x2 rv[4];
+  using RV = typename std::conditional<NW == 1, f32x2, f32x4>::type;
+  RV rv[4];
   auto reduce_issue = [&](int par) __attribute__((always_inline)) {
     const unsigned char* const sr = stg + par * STGB + r_lds;
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
-      if constexpr (DP_ROWS_EXP & 2) rv[q4] = f32x2{1.f, 2.f};
-      else rv[q4] = *reinterpret_cast<const f32x2*>(sr + q4 * 4096);
+      if constexpr (DP_ROWS_EXP & 2) { for (int i = 0; i < RN; ++i) rv[q4][i] = 1.f; }
+      else rv[q4] = *reinterpret_cast<const RV*>(sr + q4 * (2 * NW * 2 * 1024));
     }
   };
   auto reduce_finish = [&](int t, int obase, bool emit) __attribute__((always_inline)) {
-    float x0 = rv[0][0], x1 = rv[0][1];
+    float x[RN];
 #pragma unroll
-    for (int q4 = 1; q4 < 4; ++q4) { x0 += rv[q4][0]; x1 += rv[q4][1]; }     // quarter order: the summation order of a pixel is fixed
-    x0 += r_bias[0];
-    x1 += r_bias[1];
-    if (p.relu) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
-    __builtin_amdgcn_raw_buffer_store_b32(Elem<T>::pack2(x0, x1), rs_out, (emit && !(DP_ROWS_EXP & 2)) ? obase + t * out_row : OOB, 0, 0);
+    for (int i = 0; i < RN; ++i) {
+      x[i] = rv[0][i];
+#pragma unroll
+      for (int q4 = 1; q4 < 4; ++q4) x[i] += rv[q4][i];     // quarter order: the summation order of a pixel is fixed
+      x[i] += r_bias[i];
+      if (p.relu) x[i] = fmaxf(x[i], 0.f);
+    }
+    const int off = (emit && !(DP_ROWS_EXP & 2)) ? obase + t * out_row : OOB;
+    if constexpr (NW == 1) __builtin_amdgcn_raw_buffer_store_b32(Elem<T>::pack2(x[0], x[1]), rs_out, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{Elem<T>::pack2(x[0], x[1]), Elem<T>::pack2(x[2], x[3])}, rs_out, off, 0, 0);
   };
 
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -850,11 +887,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
     const unsigned char* const row0 = ring_q + c_slot + c_frag[0];
     const unsigned char* const row1 = ring_q + c_slot + c_frag[1];
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) acc[A_NEW][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < NW; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) acc[A_NEW][ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NB = 2 * NCB;                  // batches per step: (pixel tile, channel block) = 3 fragments = 9 NW MFMAs
     if (row_ok) {
-      // one straight-line block: batch (pixel tile, channel block) = 3 fragments = 9 MFMAs, the next batch's reads issued first
+      // one straight-line block, the next batch's reads issued first
       auto ld = [&](auto bb) __attribute__((always_inline)) {
-        constexpr int bi = decltype(bb)::value, pt = bi >> 2, cb = bi & 3;
+        constexpr int bi = decltype(bb)::value, pt = bi / NCB, cb = bi % NCB;
         const unsigned char* const r = pt ? row1 : row0;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
@@ -865,21 +905,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
       ld(std::integral_constant<int, 0>{});
       if constexpr (NBUF == 3) ld(std::integral_constant<int, 1>{});
       if constexpr (!(DP_ROWS2_OPT & 2)) __builtin_amdgcn_s_setprio(1);
-      static_for<0, 8>([&](auto bb) {
-        constexpr int bi = decltype(bb)::value, pt = bi >> 2, cb = bi & 3;
+      static_for<0, NB>([&](auto bb) {
+        constexpr int bi = decltype(bb)::value, pt = bi / NCB, cb = bi % NCB;
         // (fenced: left alone hipcc moves each read down to just before its first use and waits for it there - ten exposed LDS
         // latencies per step)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (bi + NBUF - 1 < 8) ld(std::integral_constant<int, bi + NBUF - 1>{});
-        if constexpr ((DP_ROWS2_OPT & 4) != 0 && bi == 4) { if (sched_y) fetch_next(); }
+        if constexpr (bi + NBUF - 1 < NB) ld(std::integral_constant<int, bi + NBUF - 1>{});
+        if constexpr ((DP_ROWS2_OPT & 4) != 0 && bi == NB / 2) { if (sched_y) fetch_next(); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          if constexpr (DP_ROWS_EXP & 4) { acc[A_OLD][pt][0] += __builtin_bit_cast(float, bf[bi % NBUF][kx][0]); }
+          if constexpr (DP_ROWS_EXP & 4) { acc[A_OLD][0][pt][0] += __builtin_bit_cast(float, bf[bi % NBUF][kx][0]); }
           else {
-            Mma<T>::run(wfr[cb * 9 + 6 + kx], bf[bi % NBUF][kx], acc[A_OLD][pt]);
-            Mma<T>::run(wfr[cb * 9 + 3 + kx], bf[bi % NBUF][kx], acc[A_MID][pt]);
-            Mma<T>::run(wfr[cb * 9 + 0 + kx], bf[bi % NBUF][kx], acc[A_NEW][pt]);
+#pragma unroll
+            for (int ct = 0; ct < NW; ++ct) {
+              Mma<T>::run(wfr[(ct * NCB + cb) * 9 + 6 + kx], bf[bi % NBUF][kx], acc[A_OLD][ct][pt]);
+              Mma<T>::run(wfr[(ct * NCB + cb) * 9 + 3 + kx], bf[bi % NBUF][kx], acc[A_MID][ct][pt]);
+              Mma<T>::run(wfr[(ct * NCB + cb) * 9 + 0 + kx], bf[bi % NBUF][kx], acc[A_NEW][ct][pt]);
+            }
           }
         }
       });
@@ -888,8 +931,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
       if (sched_y) fetch_next();
     }
     // the finished row's partial sums (whatever they are when nothing is emitted: the reduction then stores out of range)
-    *reinterpret_cast<f32x4*>(stg_w + c_par * STGB) = acc[A_OLD][0];
-    *reinterpret_cast<f32x4*>(stg_w + c_par * STGB + 1024) = acc[A_OLD][1];
+#pragma unroll
+    for (int ct = 0; ct < NW; ++ct)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) *reinterpret_cast<f32x4*>(stg_w + c_par * STGB + (ct * 2 + pt) * 1024) = acc[A_OLD][ct][pt];
   };
 
   // prologue: rows 0 and 1 staged and visible to the whole workgroup
@@ -910,7 +955,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
     if (sched_y) {
       reduce_finish(p2_t, p2_ob, s >= 2 && p2_emit);
       DP_STAMP(1)
-      asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      rows2_wait_vm<NPW + 2>();
       DP_STAMP(2)
       __builtin_amdgcn_s_barrier();
       DP_STAMP(3)
@@ -926,11 +971,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
       DP_STAMP(1)
     }
     phase_b(ph_c, s);
-    if constexpr (DP_ROWS_EXP & 16) asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[1][0][0]), "v"(acc[2][0][0]), "v"(acc[0][1][0]), "v"(acc[1][1][0]), "v"(acc[2][1][0]));
+    if constexpr (DP_ROWS_EXP & 16) asm volatile("s_nop 0" :: "v"(acc[0][0][0][0]), "v"(acc[1][0][0][0]), "v"(acc[2][0][0][0]), "v"(acc[0][NW - 1][1][0]), "v"(acc[1][NW - 1][1][0]), "v"(acc[2][NW - 1][1][0]));
     DP_STAMP(5)
     if (!sched_y) {
-      if constexpr ((DP_ROWS2_OPT & 8) != 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // store, then the pieces: one operation fewer behind row s + 1
-      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      if constexpr ((DP_ROWS2_OPT & 8) != 0) rows2_wait_vm<NPW + 1>();     // store, then the pieces: one operation fewer behind row s + 1
+      else rows2_wait_vm<NPW + 2>();
       DP_STAMP(2)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       DP_STAMP(6)
@@ -967,13 +1012,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
 #undef DP_STAMP
 }
 
-template <typename T>
+template <typename T, int CIN>
 int launch_rows2(const RowsArgs& a, hipStream_t stream) {
-  constexpr int lds = 4 * 3 * 35 * 272 + 3 * 16 * 1024;
+  constexpr int lds = 4 * 3 * 35 * (CIN / 2 + 16) + 3 * 8 * (CIN == 512 ? 1 : 2) * 2 * 1024;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_rows2_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_rows2_kernel<T, CIN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
 #if DP_ROWS_EXP & 16
@@ -983,7 +1028,7 @@ int launch_rows2(const RowsArgs& a, hipStream_t stream) {
   if (!dbg) (void)hipMalloc(&dbg, sizeof(unsigned long long) * 8 * 16 * 4096);
   b.dbg = dbg;
   (void)hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 8 * 16 * nblk, stream);
-  hipLaunchKernelGGL((conv3x3_rows2_kernel<T>), dim3(nblk), dim3(512), lds, stream, b);
+  hipLaunchKernelGGL((conv3x3_rows2_kernel<T, CIN>), dim3(nblk), dim3(512), lds, stream, b);
   {
     static int shown = 0;
     if (shown++ % 40 == 4) {   // a warm launch (and again for every further mode of tools/rows_micro.py)
@@ -1000,7 +1045,7 @@ int launch_rows2(const RowsArgs& a, hipStream_t stream) {
     }
   }
 #else
-  hipLaunchKernelGGL((conv3x3_rows2_kernel<T>), dim3(a.n_pg * a.n_slices), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((conv3x3_rows2_kernel<T, CIN>), dim3(a.n_pg * a.n_slices), dim3(512), lds, stream, a);
 #endif
   return dp_check_launch("conv3x3_rows2_kernel");
 }
@@ -1075,12 +1120,10 @@ bool rows_width_ok(int W) {
   return true;
 }
 
-// every 32-pixel strip of a group of G = 32 / gcd(W, 32) images is at most two segments from two consecutive images, and a group is at
-// most 8 images (a launch works on whole groups: 28-wide ROI maps G = 8; res5's 42-wide maps would need 16 images for 21 strips)
+// every 32-pixel strip of a group of G = 32 / gcd(W, 32) images is at most two segments from two consecutive images
 bool rows2_width_ok(int W) {
   if (W < 16) return false;
   const int G = 32 / gcd_i(W, 32), spg = G * W / 32;
-  if (G > 8) return false;
   for (int k = 0; k < spg; ++k) {
     const int c00 = (32 * k) % W, len0 = W - c00 < 32 ? W - c00 : 32;
     if (32 - len0 > W) return false;
@@ -1103,7 +1146,18 @@ bool rows2_ok(const dp_conv_params* p) {
   const char* e = getenv("DP_CONV_ROWS2");
   const char* e1 = getenv("DP_CONV_ROWS");
   if ((e && atoi(e) == 0) || (e1 && atoi(e1) == 0)) return false;
-  return p->Cin == 512 && p->Cout % 32 == 0 && p->W > 0 && rows2_width_ok(p->W) && rows_common_ok(p, 32 / gcd_i(p->W, 32));
+  if (p->W <= 0) return false;
+  const int g = 32 / gcd_i(p->W, 32);
+  // 512 channels: widths with strip groups of at most 8 images (28-wide ROI maps; res5's 42-wide maps - groups of 16 - stay on the 16-pixel
+  // form). 256 channels (64 couts per workgroup): the layers with another cout count (the DensePose head's 256 -> 512 first layer: 93 us
+  // against 105 on the LDS-ring kernel). On 256 -> 256 layers it measures the same as the weight-stationary kernel of dp_conv_ws.hip
+  // (465 / 121 / 40 us against 461 / 121 / 39 at the three FPN levels), and the DeepLab head's device-sized 256 -> 256 layers gain nothing
+  // end to end (profiles/r4_rows_kernel_experiments.txt). DP_CONV_ROWS2_256: 0 never, 1 every 256-channel layer (A/B knobs).
+  const char* e2 = getenv("DP_CONV_ROWS2_256");
+  const int m256 = e2 ? atoi(e2) : -1;
+  const bool c256 = p->Cin == 256 && p->Cout % 64 == 0 && m256 != 0 && (m256 == 1 || p->Cout != 256);
+  const bool shape = (p->Cin == 512 && p->Cout % 32 == 0 && g <= 8) || c256;
+  return shape && rows2_width_ok(p->W) && rows_common_ok(p, g);
 }
 
 }  // namespace
@@ -1136,7 +1190,7 @@ int dp_conv_rows_launch(const dp_conv_params* p, dp_stream_t stream) {
   a.G = sw / gcd_i(p->W, sw);
   a.SPG = a.G * p->W / sw;
   const int nc = p->Cin == 512 ? 32 : 64;
-  a.n_slices = p->Cout / nc;
+  a.n_slices = (p->Cout + nc - 1) / nc;
   int groups = rows_num_cus() / (8 * a.n_slices);
   if (groups < 1) groups = 1;
   a.n_pg = groups * 8;
@@ -1148,7 +1202,8 @@ int dp_conv_rows_launch(const dp_conv_params* p, dp_stream_t stream) {
   if (two) {
     const char* le = getenv("DP_CONV_ROWS2_LOCKSTEP");     // A/B knob: 1 = all eight waves on one schedule
     a.lockstep = le && atoi(le) == 1;
-    return p->dtype == DP_BF16 ? launch_rows2<uint16_t>(a, s) : launch_rows2<f16_t>(a, s);
+    if (p->Cin == 256) return p->dtype == DP_BF16 ? launch_rows2<uint16_t, 256>(a, s) : launch_rows2<f16_t, 256>(a, s);
+    return p->dtype == DP_BF16 ? launch_rows2<uint16_t, 512>(a, s) : launch_rows2<f16_t, 512>(a, s);
   }
   const char* ce = getenv("DP_CONV_ROWS_CHAIN");     // A/B knob: 1 = the barrier-free chain form for the 512-channel layers
   if (p->Cin == 512 && ce && atoi(ce) == 1) return p->dtype == DP_BF16 ? launch_chain<uint16_t>(a, s) : launch_chain<f16_t>(a, s);

@@ -514,16 +514,20 @@ ROWS_CASES = [
     (512, 512, 3, 9, 56, 2, False),
     (512, 160, 2, 30, 32, None, True),      # whole strips only
     (512, 512, 5, 7, 24, None, True),
+    (256, 256, 8, 50, 84, None, True),      # res4 conv2 / FPN p4 geometry on the 64-cout 32-pixel form (DP_CONV_ROWS2_256=1)
+    (256, 256, 2, 25, 42, None, False),     # groups of 16 images, two live: strips counted from the live columns
+    (256, 128, 3, 11, 168, 2, True),
 ]
 
 
-def _rows2_width_ok(W):
-    """mirror of rows2_width_ok (dp_conv_rows.hip): groups of at most 8 images, every 32-pixel strip at most two segments"""
+def _rows2_width_ok(W, max_group=8):
+    """mirror of rows2_width_ok / rows2_ok (dp_conv_rows.hip): every 32-pixel strip at most two segments; the 512-channel policy also
+    wants strip groups of at most 8 images"""
     import math
     if W < 16:
         return False
     G = 32 // math.gcd(W, 32)
-    if G > 8:
+    if G > max_group:
         return False
     for k in range(G * W // 32):
         c00 = (32 * k) % W
@@ -548,7 +552,7 @@ def test_conv3x3_rows_kernel(eng, dt, case, variant, monkeypatch):
     from densepose_torchscript_amd.pack import conv_from_oihw
     e = eng[dt]
     Ci, Co, N, H, W, live, relu = case
-    two_ok = Ci == 512 and _rows2_width_ok(W)
+    two_ok = (Ci == 512 and _rows2_width_ok(W)) or (Ci == 256 and _rows2_width_ok(W, 1 << 30))
     monkeypatch.delenv("DP_CONV_ROWS_CHAIN", raising=False)
     monkeypatch.delenv("DP_CONV_ROWS2_LOCKSTEP", raising=False)
     if variant == "chain":
@@ -559,6 +563,7 @@ def test_conv3x3_rows_kernel(eng, dt, case, variant, monkeypatch):
         if not two_ok:
             pytest.skip("the 32-pixel form takes 512 input channels and widths with strip groups of at most 8 images")
         monkeypatch.delenv("DP_CONV_ROWS2", raising=False)
+        monkeypatch.setenv("DP_CONV_ROWS2_256", "1")     # every 256-channel layer (default: only those the weight-stationary kernel does not take)
         if variant == "rows2_lockstep":
             monkeypatch.setenv("DP_CONV_ROWS2_LOCKSTEP", "1")
     else:
@@ -584,8 +589,12 @@ def test_conv3x3_rows_kernel(eng, dt, case, variant, monkeypatch):
     p.n_dev = None if n_dev is None else n_dev.data_ptr()
     if variant.startswith("rows2"):
         assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 8
+        # 256 input channels: by default only the layers with another cout count (the head's 256 -> 512 first layer)
+        monkeypatch.delenv("DP_CONV_ROWS2_256")
+        assert (e.lib.dp_conv2d_kernel_class(C.byref(p)) == 8) == (Ci == 512 or Co != 256)
+        monkeypatch.setenv("DP_CONV_ROWS2_256", "1")
     else:
-        assert (e.lib.dp_conv2d_kernel_class(C.byref(p)) == 7) == (Ci == 512 and live is None)
+        assert (e.lib.dp_conv2d_kernel_class(C.byref(p)) == 7) == (Ci == 512 and live is None)     # (DP_CONV_ROWS2=0 in this variant)
     p.n_dev = None
     monkeypatch.setenv("DP_CONV_ROWS", "2")
     nl = N if live is None else live

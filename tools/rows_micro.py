@@ -26,11 +26,11 @@ def run(n=100):
     for _ in range(n): e.conv(layer, xa, relu=True)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-MODES = {"ring": {"DP_CONV_ROWS": "0"}, "rows16": {"DP_CONV_ROWS": "2", "DP_CONV_ROWS2": "0"}, "rows32": {"DP_CONV_ROWS": "2", "DP_CONV_ROWS2": "1"},
-         "rows32-lockstep": {"DP_CONV_ROWS": "2", "DP_CONV_ROWS2": "1", "DP_CONV_ROWS2_LOCKSTEP": "1"}, "chain": {"DP_CONV_ROWS": "2", "DP_CONV_ROWS2": "0", "DP_CONV_ROWS_CHAIN": "1"}}
+MODES = {"ring": {"DP_CONV_ROWS": "0"}, "rows16": {"DP_CONV_ROWS": "2", "DP_CONV_ROWS2": "0"}, "rows32": {"DP_CONV_ROWS": "2", "DP_CONV_ROWS2": "1", "DP_CONV_ROWS2_256": "1"},
+         "rows32-lockstep": {"DP_CONV_ROWS": "2", "DP_CONV_ROWS2": "1", "DP_CONV_ROWS2_256": "1", "DP_CONV_ROWS2_LOCKSTEP": "1"}, "chain": {"DP_CONV_ROWS": "2", "DP_CONV_ROWS2": "0", "DP_CONV_ROWS_CHAIN": "1"}}
 names = os.environ.get("MODES", "rows32,rows32-lockstep,rows16,ring").split(",")
 def setmode(name):
-    for k in ("DP_CONV_ROWS", "DP_CONV_ROWS2", "DP_CONV_ROWS2_LOCKSTEP", "DP_CONV_ROWS_CHAIN"):
+    for k in ("DP_CONV_ROWS", "DP_CONV_ROWS2", "DP_CONV_ROWS2_LOCKSTEP", "DP_CONV_ROWS_CHAIN", "DP_CONV_ROWS2_256"):
         os.environ.pop(k, None)
     os.environ.update(MODES[name])
 # the chip's clock settles over hundreds of milliseconds: 1.5 s of the same load first, then the modes in turn, three passes
