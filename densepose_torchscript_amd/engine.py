@@ -265,8 +265,8 @@ class Engine:
                     cls = cls[:-1] + ",2src>"
                 if split_ws is not None:              # ... and the split-K form (+ its reduction pass)
                     cls = cls[:-1] + ",splitk%d>" % layer.split_k
-            if cls == "conv3x3_rows_kernel":          # ... per input channel count for the row-streaming kernel
-                cls = "conv3x3_rows_kernel<%d>" % x.C
+            if cls in ("conv3x3_rows_kernel", "conv3x3_rows2_kernel"):          # ... per input channel count for the row-streaming kernels
+                cls = "%s<%d>" % (cls, x.C)
             if cls == "conv3x3_wsr_kernel":           # ... and per (channels, ReLU) for the weight-stationary kernel
                 cls = "conv3x3_wsr_kernel<%d,%s%s>" % (x.C, "relu" if relu else "linear", ",post%d" % post_mode if post is not None else "")
             es = x.t.element_size()

@@ -32,6 +32,10 @@ def short(name):
         dt = {"unsigned short": "bf16", "_Float16": "f16"}.get(args[0], args[0])
         post = ",post%s" % args[4] if len(args) > 4 and args[4] not in ("0",) else ""
         return "conv3x3_wsr_kernel<%s,%s%s>[%s]" % (args[1], "relu" if args[3] in ("true", "1") else "linear", post, dt)
+    m = re.search(r"(conv3x3_rows2?_kernel)<([^>]*)>", name)
+    if m:   # <storage type, input channels, ...>: one line per channel count, as engine.py / bench.py name them
+        args = [a.strip() for a in m.group(2).split(",")]
+        return "%s<%s>" % (m.group(1), args[1]) if len(args) > 1 else m.group(1)
     m = re.search(r"bottleneck_tail64_kernel<([^>]*)>", name)
     if m:
         args = [a.strip() for a in m.group(1).split(",")]
