@@ -63,6 +63,7 @@ struct RowsArgs {
   unsigned in_bytes, out_bytes;
   unsigned long long* dbg;     // diagnostic builds (-DDP_ROWS_EXP=16): per-wave phase cycle sums
   int lockstep;                // conv3x3_rows2_kernel: 1 = all eight waves on one schedule (A/B knob), 0 = the two halves in opposite phases
+  int n_base;                  // first image of this launch in the caller's tensor (launches are cut into chunks below 2 GiB): *n_dev counts from there
 };
 
 template <int N>
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const RowsArgs p) 
   const int slice = (b >> 3) % p.n_slices;      // the slices of a pixel group run on one XCD (they read the same rows)
   const int pg = (b & 7) + 8 * (b / (8 * p.n_slices));
 
-  const int n_live = p.n_dev ? min(*p.n_dev, p.N) : p.N;
+  const int n_live = p.n_dev ? min(max(*p.n_dev - p.n_base, 0), p.N) : p.N;
   // whole groups of G images, then the strips that the columns of the remaining images reach (a strip is SW = G * W / SPG pixels)
   const int n_strips = (n_live / p.G) * p.SPG + ((n_live % p.G) * p.W * p.SPG + p.G * p.W - 1) / (p.G * p.W);
   const long long TR = (long long)n_strips * p.H;
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_chain_kernel(const RowsArgs p)
   const int slice = (b >> 3) % p.n_slices;
   const int pg = (b & 7) + 8 * (b / (8 * p.n_slices));
 
-  const int n_live = p.n_dev ? min(*p.n_dev, p.N) : p.N;
+  const int n_live = p.n_dev ? min(max(*p.n_dev - p.n_base, 0), p.N) : p.N;
   // whole groups of G images, then the strips that the columns of the remaining images reach (a strip is SW = G * W / SPG pixels)
   const int n_strips = (n_live / p.G) * p.SPG + ((n_live % p.G) * p.W * p.SPG + p.G * p.W - 1) / (p.G * p.W);
   const long long TR = (long long)n_strips * p.H;
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
   const int slice = (b >> 3) % p.n_slices;
   const int pg = (b & 7) + 8 * (b / (8 * p.n_slices));
 
-  const int n_live = p.n_dev ? min(*p.n_dev, p.N) : p.N;
+  const int n_live = p.n_dev ? min(max(*p.n_dev - p.n_base, 0), p.N) : p.N;
   // whole groups of G images, then the strips that the columns of the remaining images reach (a strip is SW = G * W / SPG pixels)
   const int n_strips = (n_live / p.G) * p.SPG + ((n_live % p.G) * p.W * p.SPG + p.G * p.W - 1) / (p.G * p.W);
   const long long TR = (long long)n_strips * p.H;
@@ -1137,7 +1138,7 @@ bool rows_common_ok(const dp_conv_params* p, int g) {
          !p->residual && !p->out_f32 && !p->head_out && !p->in2 && !p->post_res && p->post_mode == 0 && p->split_k <= 1 && p->out &&
          p->osW >= p->Cout && p->osW % 8 == 0 && p->osH == (long long)p->W * p->osW && p->osN == (long long)p->H * p->W * p->osW &&
          p->Cout <= p->Cout_w && p->Cout_w % 64 == 0 &&
-         (long long)(p->N + g) * p->H * p->W * p->Cin * 2 < (1ll << 31) && (long long)(p->N + g) * p->H * p->W * p->osW * 2 < (1ll << 31);
+         (long long)(2 * g) * p->H * p->W * p->Cin * 2 < (1ll << 30) && (long long)(2 * g) * p->H * p->W * p->osW * 2 < (1ll << 30);
 }
 
 // the 32-pixel form: 512 input channels and a width whose strip groups are small (decided by the geometry alone: its summation order
@@ -1181,31 +1182,55 @@ bool dp_conv_rows_ok(const dp_conv_params* p) {
 
 bool dp_conv_rows2_ok(const dp_conv_params* p) { return rows2_ok(p); }
 
+// 32-bit buffer offsets inside the kernels: a launch whose tensors exceed 2 GiB (thousands of ROI slots) goes as several launches over
+// chunks of whole strip groups - NOT to another kernel class: these kernels' summation order is their own, and an image's result
+// must not depend on how many others are in the batch. DP_ROWS_CHUNK_BYTES (tests) lowers the limit.
 int dp_conv_rows_launch(const dp_conv_params* p, dp_stream_t stream) {
   RowsArgs a;
-  a.in = p->in; a.w = p->weight; a.bias = p->bias; a.out = p->out; a.n_dev = p->n_dev;
-  a.N = p->N; a.H = p->H; a.W = p->W; a.relu = p->relu; a.opitch = (int)p->osW; a.kpad = p->Kpad;
+  a.w = p->weight; a.bias = p->bias; a.n_dev = p->n_dev;
+  a.H = p->H; a.W = p->W; a.relu = p->relu; a.opitch = (int)p->osW; a.kpad = p->Kpad;
   const bool two = rows2_ok(p);
   const int sw = two ? 32 : 16;
   a.G = sw / gcd_i(p->W, sw);
   a.SPG = a.G * p->W / sw;
   const int nc = p->Cin == 512 ? 32 : 64;
-  a.n_slices = (p->Cout + nc - 1) / nc;
+  a.n_slices = p->Cout / nc;
   int groups = rows_num_cus() / (8 * a.n_slices);
   if (groups < 1) groups = 1;
   a.n_pg = groups * 8;
   a.dbg = nullptr;
   a.lockstep = 0;
-  a.in_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cin * 2);
-  a.out_bytes = (unsigned)((long long)p->N * p->H * p->W * p->osW * 2);
   hipStream_t s = as_stream(stream);
-  if (two) {
-    const char* le = getenv("DP_CONV_ROWS2_LOCKSTEP");     // A/B knob: 1 = all eight waves on one schedule
-    a.lockstep = le && atoi(le) == 1;
-    if (p->Cin == 256) return p->dtype == DP_BF16 ? launch_rows2<uint16_t, 256>(a, s) : launch_rows2<f16_t, 256>(a, s);
-    return p->dtype == DP_BF16 ? launch_rows2<uint16_t, 512>(a, s) : launch_rows2<f16_t, 512>(a, s);
+  const char* le = getenv("DP_CONV_ROWS2_LOCKSTEP");     // A/B knob: 1 = all eight waves on one schedule
+  if (two) a.lockstep = le && atoi(le) == 1;
+  const char* ce = getenv("DP_CONV_ROWS_CHAIN");         // A/B knob: 1 = the barrier-free chain form for the 512-channel layers
+  const bool chain = !two && p->Cin == 512 && ce && atoi(ce) == 1;
+  const long long in_img = (long long)p->H * p->W * p->Cin * 2, out_img = (long long)p->H * p->W * p->osW * 2;
+  const char* lim_e = getenv("DP_ROWS_CHUNK_BYTES");
+  long long lim = lim_e ? atoll(lim_e) : (1ll << 31) - 1;
+  if (lim < 1) lim = 1;
+  long long per = lim / (in_img > out_img ? in_img : out_img);
+  per = per / a.G * a.G;                                 // whole strip groups
+  if (per < a.G) per = a.G;
+  for (long long n0 = 0; n0 < p->N || n0 == 0; n0 += per) {
+    const int n = (int)(p->N - n0 < per ? p->N - n0 : per);
+    if (n <= 0) break;
+    a.in = reinterpret_cast<const unsigned char*>(p->in) + n0 * in_img;
+    a.out = reinterpret_cast<unsigned char*>(p->out) + n0 * out_img;
+    a.N = n;
+    a.n_base = (int)n0;
+    a.in_bytes = (unsigned)(n * in_img);
+    a.out_bytes = (unsigned)(n * out_img);
+    int rc;
+    if (two) {
+      if (p->Cin == 256) rc = p->dtype == DP_BF16 ? launch_rows2<uint16_t, 256>(a, s) : launch_rows2<f16_t, 256>(a, s);
+      else rc = p->dtype == DP_BF16 ? launch_rows2<uint16_t, 512>(a, s) : launch_rows2<f16_t, 512>(a, s);
+    } else if (chain) {
+      rc = p->dtype == DP_BF16 ? launch_chain<uint16_t>(a, s) : launch_chain<f16_t>(a, s);
+    } else {
+      rc = p->dtype == DP_BF16 ? launch_rows<uint16_t>(a, p->Cin, s) : launch_rows<f16_t>(a, p->Cin, s);
+    }
+    if (rc != DP_OK) return rc;
   }
-  const char* ce = getenv("DP_CONV_ROWS_CHAIN");     // A/B knob: 1 = the barrier-free chain form for the 512-channel layers
-  if (p->Cin == 512 && ce && atoi(ce) == 1) return p->dtype == DP_BF16 ? launch_chain<uint16_t>(a, s) : launch_chain<f16_t>(a, s);
-  return p->dtype == DP_BF16 ? launch_rows<uint16_t>(a, p->Cin, s) : launch_rows<f16_t>(a, p->Cin, s);
+  return DP_OK;
 }

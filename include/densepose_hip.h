@@ -148,7 +148,9 @@ int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
  * its work from the live image count, and its per-pixel summation order - fixed, but not the other kernels' - is why a layer it
  * takes runs on it for EVERY batch size), 8 = the same with 32 pixels per step and the waves split 4 K quarters x 2 cout halves (512
  * input channels on maps whose width gives strip groups of at most 8 images, e.g. the DensePose head's 28-wide ROI maps, with or
- * without n_dev; chosen by the geometry alone, its summation order differs from class 7's) - profiling / roofline bookkeeping only */
+ * without n_dev, and the 256 -> 512 first layer of that head on a 64-cout instance; chosen by the geometry alone, its summation order
+ * differs from class 7's; classes 7 / 8 cut a launch whose tensors exceed 2 GiB into several launches over chunks of whole strip groups
+ * instead of handing it to another class) - profiling / roofline bookkeeping only */
 int dp_conv2d_kernel_class(const dp_conv_params* p);
 /* pixel rows of the tile dp_conv2d_nhwc will use for these parameters (the 256-cout ring kernel picks 128 .. 256 rows in
  * steps of 32 to fit the launch into whole rounds of the chip) - profiling / roofline bookkeeping only */

@@ -611,6 +611,14 @@ def test_conv3x3_rows_kernel(eng, dt, case, variant, monkeypatch):
     for i in sorted({0, nl // 2, nl - 1} & set(range(nl))):
         one = e.conv(layer, Act(xa.t[i:i + 1].contiguous(), 1, H, W, Ci), relu=relu)
         assert torch.equal(one.t[0], got.t[i]), i
+    # a launch whose tensors exceed the 32-bit offset range goes as several launches over chunks of whole strip groups (never to
+    # another kernel class): the limit lowered to a few images, same bits, same untouched slots, the live count cut across chunks
+    monkeypatch.setenv("DP_ROWS_CHUNK_BYTES", str(3 * H * W * max(Ci, Co) * 2))
+    out2 = torch.full((N, H, W, Co), 7.0, dtype=e.tdt, device=e.device)
+    got2 = e.conv(layer, xa, relu=relu, out=out2, n_dev=n_dev)
+    torch.cuda.synchronize()
+    assert torch.equal(got2.t, got.t)
+    monkeypatch.delenv("DP_ROWS_CHUNK_BYTES")
     # the ring kernels on the same operands: equal up to the summation order
     monkeypatch.setenv("DP_CONV_ROWS", "0")
     assert e.lib.dp_conv2d_kernel_class(C.byref(p)) not in (7, 8)
