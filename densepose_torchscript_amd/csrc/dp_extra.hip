@@ -11,6 +11,39 @@ namespace {
 constexpr int kMaxResizeBatch = 64;
 struct ResizeSrcs { const uint8_t* p[kMaxResizeBatch]; };
 
+// dp_preprocess_u8 (paired layout) reading n separate frames instead of one stacked tensor: grid (cell blocks, Hp rows, frames). The same
+// expressions as preprocess_paired_kernel (dp_ops.hip): bit-identical output.
+template <typename T, bool HWC>
+__global__ void preprocess_paired_frames_kernel(const ResizeSrcs srcs, T* __restrict__ dst, int h, int w, int Hp, int Wq, float m0, float m1,
+                                                float m2, float s0, float s1, float s2) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Wq) return;
+  const int y = blockIdx.y, n = blockIdx.z;
+  const uint8_t* __restrict__ src = srcs.p[n];
+  float4 px[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int x = 2 * j + e - 3;
+    px[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y < h && x >= 0 && x < w) {
+      int v0, v1, v2;
+      if constexpr (HWC) {
+        const uint8_t* s = src + ((long long)y * w + x) * 3;
+        v0 = s[0]; v1 = s[1]; v2 = s[2];
+      } else {
+        const uint8_t* s = src + (long long)y * w + x;
+        v0 = s[0]; v1 = s[(long long)h * w]; v2 = s[2ll * h * w];
+      }
+      px[e].x = ((float)v0 - m0) / s0;
+      px[e].y = ((float)v1 - m1) / s1;
+      px[e].z = ((float)v2 - m2) / s2;
+    }
+  }
+  T* d = dst + (((long long)n * Hp + y) * Wq + j) * 8;
+  store4(d, px[0]);
+  store4(d + 4, px[1]);
+}
+
 // each thread produces 4 consecutive output bytes of a row (one 4-byte store when the row pitch allows it)
 __device__ __forceinline__ void put4(uint8_t* d, int xo, int ow, const int (&v)[4]) {
   if (xo + 3 < ow && ((reinterpret_cast<uintptr_t>(d + xo) & 3) == 0)) {
@@ -251,6 +284,32 @@ extern "C" int dp_resize_preprocess_u8_batch(const dp_resize_params* p, const vo
                          q->mean[0], q->mean[1], q->mean[2], q->std[0], q->std[1], q->std[2]);
   }
   return dp_check_launch("resize_v_preprocess_paired_kernel");
+}
+
+extern "C" int dp_preprocess_u8_frames(const dp_preprocess_params* q, const void* const* srcs, int n, dp_stream_t stream) {
+  DP_REQUIRE(q && q->dst && srcs, "dp_preprocess_u8_frames: null pointer");
+  DP_REQUIRE(n > 0 && n <= kMaxResizeBatch, "dp_preprocess_u8_frames: 1 .. %d frames per call", kMaxResizeBatch);
+  DP_REQUIRE(q->paired == 1 && q->n_img == n && q->h > 0 && q->w > 0 && q->Hp >= q->h && q->Wp >= q->w && q->Wp % 2 == 0 && q->Hp < 65536,
+             "dp_preprocess_u8_frames: the parameters must describe n frames in the paired layout");
+  DP_REQUIRE(q->dtype == DP_F32 || q->dtype == DP_BF16 || q->dtype == DP_F16, "dp_preprocess_u8_frames: bad dtype");
+  hipStream_t s = as_stream(stream);
+  ResizeSrcs a;
+  for (int i = 0; i < n; ++i) {
+    DP_REQUIRE(srcs[i], "dp_preprocess_u8_frames: null frame %d", i);
+    a.p[i] = static_cast<const uint8_t*>(srcs[i]);
+  }
+  const int Wq = q->Wp / 2 + 3;
+  const dim3 g((Wq + 255) / 256, q->Hp, n);
+#define DP_PPF(T, HWC)                                                                                                                        \
+  hipLaunchKernelGGL((preprocess_paired_frames_kernel<T, HWC>), g, dim3(256), 0, s, a, (T*)q->dst, q->h, q->w, q->Hp, Wq, q->mean[0], q->mean[1], \
+                     q->mean[2], q->std[0], q->std[1], q->std[2])
+  if (q->src_hwc) {
+    if (q->dtype == DP_F32) DP_PPF(float, true); else if (q->dtype == DP_BF16) DP_PPF(uint16_t, true); else DP_PPF(f16_t, true);
+  } else {
+    if (q->dtype == DP_F32) DP_PPF(float, false); else if (q->dtype == DP_BF16) DP_PPF(uint16_t, false); else DP_PPF(f16_t, false);
+  }
+#undef DP_PPF
+  return dp_check_launch("preprocess_paired_frames_kernel");
 }
 
 extern "C" int dp_iuv_extract(const dp_iuv_extract_params* p, dp_stream_t stream) {

@@ -85,6 +85,7 @@ class Engine:
         # capture_end on ROCm 7.2) - so only the RPN levels are forked by default (DP_FORK overrides, for experiments)
         import os as _os
         self.fork_levels = int(_os.environ.get("DP_FORK", "2"))
+        self.frames_direct = _os.environ.get("DP_FRAMES_DIRECT", "1") != "0"     # A/B knob: 0 = stack the frames of a batch first (round 3)
         self._forked = {}
         self.fuse_stem_pool = True    # stem conv + ReLU + max-pool in one launch (dp_stem_pool_nhwc)
         self.fuse_rpn_head = True     # RPN 3x3 conv + 1x1 heads in one launch where the 256-cout ring kernel runs the level
@@ -407,6 +408,22 @@ class Engine:
             p.std[i] = self.cfg.pixel_std[i]
         L.check(self.lib.dp_preprocess_u8(C.byref(p), self._stream()), "dp_preprocess_u8")
         return Act(out, n, Hp, Wq, 8)
+
+    def preprocess_frames(self, frames, hwc, x):
+        """The same for n <= 64 frames of the test size that live in separate allocations, written into the given paired-layout
+        tensor x [n, Hp, Wq, 8] (dp_preprocess_u8_frames): no stacked uint8 copy of the batch in front of the graph."""
+        n, Hp, Wq = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+        f0 = frames[0]
+        h, w = (int(f0.shape[0]), int(f0.shape[1])) if hwc else (int(f0.shape[1]), int(f0.shape[2]))
+        assert len(frames) == n and all(f.shape == f0.shape and f.dtype == torch.uint8 and f.is_cuda and f.is_contiguous() for f in frames)
+        p = L.PreprocessParams()
+        p.src, p.dst, p.paired, p.src_hwc = None, x.data_ptr(), 1, 1 if hwc else 0
+        p.n_img, p.h, p.w, p.Hp, p.Wp, p.dtype = n, h, w, Hp, 2 * (Wq - 3), self.dt
+        for i in range(3):
+            p.mean[i] = self.cfg.pixel_mean[i]
+            p.std[i] = self.cfg.pixel_std[i]
+        srcs = (C.c_void_p * n)(*[f.data_ptr() for f in frames])
+        L.check(self.lib.dp_preprocess_u8_frames(C.byref(p), srcs, n, self._stream()), "dp_preprocess_u8_frames")
 
     def backbone(self, x):
         Ls = self.model.layers
@@ -865,12 +882,15 @@ class Engine:
         fused = images_u8 if isinstance(images_u8, FusedResize) else None
         if fused is not None:
             shape = ("fused",) + tuple(fused.shape)
-        elif isinstance(images_u8, (list, tuple)):      # separate same-size device frames: gathered straight into the batch buffer
+        elif isinstance(images_u8, (list, tuple)):      # separate same-size device frames: read where they are by the preprocess launch
             frames, shape = images_u8, (len(images_u8),) + tuple(images_u8[0].shape)
         else:
             shape = tuple(images_u8.shape)
         n = shape[1] if fused is not None else shape[0]
         graphable = self.use_graphs and given_boxes is None and not self.keep_intermediates and self.prof is None and self.trace is None
+        frames_direct = graphable and frames is not None and len(frames) <= 64 and self.frames_direct and all(f.is_contiguous() for f in frames)
+        if frames_direct:
+            shape = ("frames",) + shape
         if not graphable:
             if frames is not None:
                 images_u8 = torch.stack(frames)
@@ -902,6 +922,13 @@ class Engine:
                     xs = self._empty((n, round_up(fh, 32), round_up(fw, 32) // 2 + 3, 8))
                     fused.run(self, xs)
                     static_in = ("x", xs, fh, fw)
+                elif frames_direct:
+                    # ... and behind the preprocess launch that reads the separate frames of a batch where they are (their addresses
+                    # change every step; a stacked uint8 copy of the batch would cost 3 h w n bytes of traffic per step)
+                    fh, fw = (shape[2], shape[3]) if hwc else (shape[3], shape[4])      # shape = ("frames", n) + one frame's shape
+                    xs = self._empty((n, round_up(fh, 32), round_up(fw, 32) // 2 + 3, 8))
+                    self.preprocess_frames(frames, hwc, xs)
+                    static_in = ("x", xs, fh, fw)
                 else:
                     static_in = torch.stack(frames) if frames is not None else images_u8.clone()
                 self._phase_a(static_in, None, hwc)   # eager warm-up: one-time attribute / table initialisation outside capture
@@ -920,6 +947,8 @@ class Engine:
             graph, static_in, st, pinned, flops, _ = entry
             if fused is not None:
                 fused.run(self, static_in[1])           # horizontal pass + (vertical pass, normalise, pad, layout) into the graph's input
+            elif frames_direct:
+                self.preprocess_frames(frames, hwc, static_in[1])
             elif frames is not None:
                 torch.stack(frames, out=static_in)      # one gather kernel: the frames land in the graph's input directly
             else:

@@ -164,6 +164,7 @@ SYMBOLS = {
     "dp_resize_u8_bilinear": (c_int, [C.POINTER(ResizeParams), c_void_p]),
     "dp_resize_u8_bilinear_batch": (c_int, [C.POINTER(ResizeParams), C.POINTER(c_void_p), c_int, c_void_p]),
     "dp_resize_preprocess_u8_batch": (c_int, [C.POINTER(ResizeParams), C.POINTER(c_void_p), c_int, C.POINTER(PreprocessParams), c_void_p]),
+    "dp_preprocess_u8_frames": (c_int, [C.POINTER(PreprocessParams), C.POINTER(c_void_p), c_int, c_void_p]),
     "dp_iuv_extract": (c_int, [C.POINTER(IuvExtractParams), c_void_p]),
 }
 

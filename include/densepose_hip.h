@@ -403,6 +403,11 @@ int dp_resize_u8_bilinear_batch(const dp_resize_params* p, const void* const* sr
  * q->h / q->w = p->oh / p->ow, q->n_img = n <= 64; q->src and p->dst are ignored): the resized uint8 batch is never written. Bit-identical
  * to dp_resize_u8_bilinear_batch followed by dp_preprocess_u8. */
 int dp_resize_preprocess_u8_batch(const dp_resize_params* p, const void* const* srcs, int n, const dp_preprocess_params* q, dp_stream_t stream);
+/* (ABI 5) rcnn.py:156-181 for n <= 64 frames that already have the test size (defaults.py:84-89 is the identity at scale 1), each in its own
+ * allocation: dp_preprocess_u8 in the paired layout with srcs = host array of n device pointers instead of one stacked tensor (q->src is
+ * ignored, q->paired must be 1, q->n_img = n, q->src_hwc says whether a frame is [h][w][3] or [3][h][w]). Bit-identical to stacking the
+ * frames and calling dp_preprocess_u8 - without the 3 * h * w * n byte copy in front of every batch. */
+int dp_preprocess_u8_frames(const dp_preprocess_params* q, const void* const* srcs, int n, dp_stream_t stream);
 
 typedef struct {
   const float* coarse; const float* fine; const float* u; const float* v; /* [R][C][S][S] */

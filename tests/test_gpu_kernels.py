@@ -1236,3 +1236,20 @@ def test_resize_and_iuv_extract(eng):
         assert torch.allclose(u_, ref[r][1], atol=1e-6, rtol=0), r
         if w >= 63:
             assert torch.equal(u_, ref[r][1]), r
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("hwc", [True, False])
+def test_preprocess_frames_equals_preprocess_of_the_stacked_batch(eng, dt, hwc):
+    """dp_preprocess_u8_frames (ABI 5): rcnn.py:156-181 on n separate frames of the test size == dp_preprocess_u8 on the stacked
+    batch, bit for bit (paired layout, interleaved and planar frames, ragged padding)."""
+    e = eng[dt]
+    g = torch.Generator().manual_seed(7)
+    n, h, w = 5, 37, 51
+    shape = (h, w, 3) if hwc else (3, h, w)
+    frames = [torch.randint(0, 256, shape, generator=g, dtype=torch.uint8).to(e.device) for _ in range(n)]
+    Hp, Wp = 64, 64
+    want = e.preprocess(torch.stack(frames), Hp, Wp, hwc=hwc)
+    got = torch.full_like(want.t, 3.0)
+    e.preprocess_frames(frames, hwc, got)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want.t)
