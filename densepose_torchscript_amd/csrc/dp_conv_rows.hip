@@ -680,6 +680,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows2_kernel(const RowsArgs p)
   constexpr int STGB = 8 * NW * 2 * 1024;       // staging bytes per parity: [kq][ch][cout tile][pixel tile][lane] x 16 B
   constexpr int OOB = (int)0x80000000;
   static_assert(ROWB % 16 == 0 && RING + 3 * STGB <= 160 * 1024, "LDS budget");
+  // the counted vmcnt waits below assume that EVERY wave issues exactly NPW pieces per row: the last piece of either wave must have at
+  // least one live lane (a wave-wide empty exec would be branched around and not counted)
+  static_assert((NPW - 1) * 1024 < WOFF && WOFF + (NPW - 1) * 1024 < ROWB && WOFF % 16 == 0, "every wave issues NPW pieces");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
