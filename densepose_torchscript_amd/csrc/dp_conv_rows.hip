@@ -1160,7 +1160,9 @@ bool rows2_ok(const dp_conv_params* p) {
   const char* e2 = getenv("DP_CONV_ROWS2_256");
   const int m256 = e2 ? atoi(e2) : -1;
   const bool c256 = p->Cin == 256 && p->Cout % 64 == 0 && m256 != 0 && (m256 == 1 || p->Cout != 256);
-  const bool shape = (p->Cin == 512 && p->Cout % 32 == 0 && g <= 8) || c256;
+  const char* eg = getenv("DP_CONV_ROWS2_MAXG");       // experiments: largest strip group the 512-channel layers take (default 8)
+  const int maxg = eg ? atoi(eg) : 8;
+  const bool shape = (p->Cin == 512 && p->Cout % 32 == 0 && g <= maxg) || c256;
   return shape && rows2_width_ok(p->W) && rows_common_ok(p, g);
 }
 
