@@ -524,10 +524,17 @@ bool dp_conv_wsr_ok(const dp_conv_params* p) {
   const long long M = (long long)p->N * p->H * p->W;
   const bool shape = (p->Cin == 128 && p->Cout == 128 && p->Cout_w == 128) || (p->Cin == 256 && p->Cout == 256 && p->Cout_w == 256);
   const int rp = p->Cin == 128 ? kWsrRP128 : kWsrRP256;
+  // fewest output pixels of a launch the kernel takes (DP_WS_MIN_M: calibration knob). Round 2 drew the line at 2048; measured again at
+  // batch 1 (one 25 x 42 / 13 x 21 map: the p5 / p6 levels of a single frame) the ring kernel needs 27 / 26 us for its 72 K planes, this
+  // kernel 12 / 10 us - same bits either way, so the line only moves time
+  const char* em = getenv("DP_WS_MIN_M");
+  // (launches with a post tensor keep the old line: whether the decoder's level sum is folded into the convolutions - a per-geometry
+  // choice that moves rounding points - is decided by asking this function, and that choice stays what the parity tests pinned)
+  const long long min_m = p->post_res ? 2048 : (em ? atoll(em) : 256);
   return (p->dtype == DP_BF16 || p->dtype == DP_F16) && !p->n_dev && shape && p->ntaps == 9 && p->Kpad == 9 * p->Cin && p->stride == 1 &&
          (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == -1 && p->wi_off == -1 && p->H == p->Ho && p->W == p->Wo &&
          !p->residual && !p->out_f32 && !p->head_out && p->out && p->osW == p->Cout && p->osH == (long long)p->W * p->Cout &&
-         p->osN == (long long)p->H * p->W * p->Cout && p->H >= 2 * rp && M >= 2048 && M * 2 * p->Cin < (1ll << 31) &&
+         p->osN == (long long)p->H * p->W * p->Cout && p->H >= 2 * rp && M >= min_m && M * 2 * p->Cin < (1ll << 31) &&
          (p->post_res == nullptr ? p->post_mode == 0
                                  : (p->Cin == 256 && p->relu && (p->post_mode == 1 || (p->post_mode == 2 && p->H % 2 == 0 && p->W % 2 == 0))));
 }
