@@ -214,6 +214,58 @@ __global__ __launch_bounds__(256) void iuv_upsample_split_kernel(const float* __
   __syncthreads();
   const int Ho = 2 * Hs, Wo = 2 * Ws, Ctot = n_coarse + 3 * n_fine;
   const long long hw = (long long)Ho * Wo;
+  if (xslots < 0) {
+    // FOUR consecutive outputs of a row per thread (Wo % 4 == 0: one 16-byte store per thread, a channel's row segment of a wave is
+    // contiguous): outputs 4q .. 4q + 3 interpolate between the source columns 2q - 1 .. 2q + 2 - eight LDS reads instead of sixteen.
+    // Every output is still computed by the expression of the one-output form below, on the same four samples: bit-identical.
+    const int qslots = -xslots;                      // power of two >= Wo / 4
+    const int q = threadIdx.x & (qslots - 1), cl = threadIdx.x / qslots, n_cl = 256 / qslots;
+    if (4 * q >= Wo) return;
+    int xa[4], xb[4];
+    float lx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bil_src(4 * q + e, Ws, xa[e], xb[e], lx[e]);
+    for (int k = 0; k < 2; ++k) {
+      const int yo = 2 * i + 1 + k;
+      if (yo < 0 || yo >= Ho) continue;
+      int yy0, yy1;
+      float ly;
+      bil_src(yo, Hs, yy0, yy1, ly);
+      const float hy = 1.f - ly;
+      const long long pix = (long long)yo * Wo + 4 * q;
+      for (int c = cl; c < Ctot; c += n_cl) {
+        const float* ra = rows + c * pitch;
+        // source columns xa[0] = max(2q - 1, 0) .. xb[3] = min(2q + 2, Ws - 1): read once, picked per output
+        const int c0 = xa[0];
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = min(c0 + j, Ws - 1);
+          t0[j] = ra[col];
+          t1[j] = ra[plane + col];
+        }
+        float4 val;
+        float* vp = &val.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ia = xa[e] - c0, ib = xb[e] - c0;       // 0 .. 3
+          const float a = ia == 0 ? t0[0] : ia == 1 ? t0[1] : ia == 2 ? t0[2] : t0[3];
+          const float b = ib == 0 ? t0[0] : ib == 1 ? t0[1] : ib == 2 ? t0[2] : t0[3];
+          const float cc = ia == 0 ? t1[0] : ia == 1 ? t1[1] : ia == 2 ? t1[2] : t1[3];
+          const float d = ib == 0 ? t1[0] : ib == 1 ? t1[1] : ib == 2 ? t1[2] : t1[3];
+          const float hx = 1.f - lx[e];
+          vp[e] = hy * (hx * a + lx[e] * b) + ly * (hx * cc + lx[e] * d);
+        }
+        float* dst;
+        if (c < n_coarse) dst = coarse + ((long long)r * n_coarse + c) * hw + pix;
+        else if (c < n_coarse + n_fine) dst = fine + ((long long)r * n_fine + (c - n_coarse)) * hw + pix;
+        else if (c < n_coarse + 2 * n_fine) dst = u + ((long long)r * n_fine + (c - n_coarse - n_fine)) * hw + pix;
+        else dst = v + ((long long)r * n_fine + (c - n_coarse - 2 * n_fine)) * hw + pix;
+        *reinterpret_cast<float4*>(dst) = val;
+      }
+    }
+    return;
+  }
   // thread = (x slot, channel lane): the horizontal taps are computed once per thread, the channel is wave-uniform (the
   // x slots of a channel lane span whole waves), so the loop body is 4 LDS reads + the lerp + one coalesced store
   const int xo = threadIdx.x & (xslots - 1), cl = threadIdx.x / xslots, n_cl = 256 / xslots;
@@ -678,6 +730,16 @@ extern "C" int dp_iuv_upsample_split(const dp_iuv_params* p, dp_stream_t stream)
   DP_REQUIRE(2 * p->Ws <= 256, "dp_iuv_upsample_split: output rows wider than 256");
   int xslots = 64;   // power of two >= the output width: a channel lane covers whole waves
   while (xslots < 2 * p->Ws) xslots *= 2;
+  // four outputs per thread and 16-byte stores when every output row starts on a 16-byte boundary (A/B knob DP_IUV_QUAD=0);
+  // passed as a negative slot count = - (power of two >= output width / 4)
+  const char* qe = getenv("DP_IUV_QUAD");
+  const bool al16 = ((reinterpret_cast<uintptr_t>(p->coarse) | reinterpret_cast<uintptr_t>(p->fine) | reinterpret_cast<uintptr_t>(p->u) |
+                      reinterpret_cast<uintptr_t>(p->v)) & 15) == 0;
+  if ((2 * p->Ws) % 4 == 0 && al16 && !(qe && atoi(qe) == 0)) {
+    int qs = 16;
+    while (qs < (2 * p->Ws) / 4) qs *= 2;
+    xslots = -qs;
+  }
   hipLaunchKernelGGL(iuv_upsample_split_kernel, dim3(p->Hs + 1, p->R), dim3(256), lds, as_stream(stream), p->in, p->R, p->Hs, p->Ws,
                      p->in_c, p->n_coarse, p->n_fine, p->coarse, p->fine, p->u, p->v, xslots, p->r_dev);
   return dp_check_launch("iuv_upsample_split_kernel");

@@ -1253,3 +1253,37 @@ def test_preprocess_frames_equals_preprocess_of_the_stacked_batch(eng, dt, hwc):
     e.preprocess_frames(frames, hwc, got)
     torch.cuda.synchronize()
     assert torch.equal(got, want.t)
+
+@pytest.mark.parametrize("geom", [(5, 56, 56, 80, 2, 25), (3, 28, 28, 96, 15, 25), (2, 9, 13, 80, 2, 25), (4, 7, 10, 80, 2, 25)])
+def test_iuv_upsample_split_forms_and_torch(eng, geom, monkeypatch):
+    """dp_iuv_upsample_split (chart_predictor.py:45-70: bilinear x2 of the four predictor outputs, NHWC -> four NCHW tensors): the
+    four-outputs-per-thread form with 16-byte stores (widths that are a multiple of 4) == the one-output form bit for bit, both ==
+    F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) on the channel slices; a device-side live count leaves the
+    slots behind it untouched."""
+    import ctypes as C
+    from densepose_torchscript_amd import lib as L
+    e = eng["fp32"]
+    R, Hs, Ws, Ci, nc, nf = geom
+    g = torch.Generator().manual_seed(R * 100 + Ws)
+    low = torch.randn((R, Hs, Ws, Ci), generator=g).to(e.device)
+    live = torch.tensor([R - 1], dtype=torch.int32, device=e.device)
+    outs = {}
+    for quad in ("1", "0"):
+        monkeypatch.setenv("DP_IUV_QUAD", quad)
+        S0, S1 = 2 * Hs, 2 * Ws
+        t = [torch.full((R, n, S0, S1), 7.0, device=e.device) for n in (nc, nf, nf, nf)]
+        p = L.IuvParams()
+        p.in_, p.R, p.Hs, p.Ws, p.in_c, p.n_coarse, p.n_fine = low.data_ptr(), R, Hs, Ws, Ci, nc, nf
+        p.coarse, p.fine, p.u, p.v = [x.data_ptr() for x in t]
+        p.r_dev = live.data_ptr()
+        L.check(e.lib.dp_iuv_upsample_split(C.byref(p), e._stream()), "dp_iuv_upsample_split")
+        torch.cuda.synchronize()
+        outs[quad] = t
+    ref = F.interpolate(low.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)
+    c0 = 0
+    for k, n in enumerate((nc, nf, nf, nf)):
+        a, b = outs["1"][k], outs["0"][k]
+        assert torch.equal(a, b), k
+        assert bool((a[R - 1] == 7.0).all())                      # the slot behind the live count
+        assert torch.allclose(a[:R - 1], ref[:R - 1, c0:c0 + n], atol=1e-5, rtol=1e-5), k
+        c0 += n
