@@ -1176,6 +1176,15 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
     const long long t128 = ((M + 127) / 128) * (p->Cout / 256);
     if (t128 >= 128) return DP_CONV_RING256;
   }
+  // Cout not a multiple of 256 on MANY pixels (the chart predictor's sub-pixel convolutions on hundreds of ROIs): the 256x128 tile with
+  // two workgroups per CU puts four waves on a SIMD behind the same per-plane latency and wins 6 - 8 % from ~230 k pixels on
+  // (512 -> 80 on N x 28 x 28: N = 300 / 400 / 600 / 800: 279 / 365 / 534 / 710 us against 304 / 392 / 569 / 767; N = 64: 102 against 76).
+  // Same K order as every ring tile: the choice may depend on the pixel count. DP_CONV_RING2_M: the line (0 = never).
+  {
+    const char* r2 = getenv("DP_CONV_RING2_M");
+    const long long line = r2 ? atoll(r2) : 230000;
+    if (line > 0 && M >= line && p->Cout > 64) return DP_CONV_RING256x128;
+  }
   return DP_CONV_RING128;
 }
 
