@@ -1287,3 +1287,35 @@ def test_iuv_upsample_split_forms_and_torch(eng, geom, monkeypatch):
         assert bool((a[R - 1] == 7.0).all())                      # the slot behind the live count
         assert torch.allclose(a[:R - 1], ref[:R - 1, c0:c0 + n], atol=1e-5, rtol=1e-5), k
         c0 += n
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("C_", [256, 128])
+def test_conv3x3_wsr_small_maps_equal_the_ring_kernel(eng, dt, C_, monkeypatch):
+    """Round 4 lowered the weight-stationary 3x3 kernel's size line to 256 output pixels per launch (a single frame's p5 / p6 levels,
+    fpn.py:134-135 / rpn.py:168 on 25 x 42 and 13 x 21 maps): on small, narrow and ragged maps it must equal the LDS-ring kernel bit for
+    bit (the same K order) - which is why that line may depend on the batch."""
+    from densepose_torchscript_amd import lib as L
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    e = eng[dt]
+    g = torch.Generator().manual_seed(C_)
+    w = _round(torch.randn((C_, C_, 3, 3), generator=g) * (1.0 / (9 * C_)) ** 0.5, dt)
+    b = torch.randn((C_,), generator=g) * 0.1
+    layer = conv_from_oihw("l", w.numpy(), b.numpy(), C_, 1, 1, 1, e.dt, e.device)
+    for (N, H, W) in [(3, 8, 13), (1, 13, 21), (1, 25, 42), (2, 7, 9), (1, 6, 16), (2, 9, 17), (1, 12, 33)]:
+        x = Act(_nhwc(_round(torch.randn((N, C_, H, W), generator=g), dt), C_, e.tdt, e.device), N, H, W, C_)
+        p = L.ConvParams()
+        p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, C_, H, W, C_, layer.cout_w, 9 * C_
+        p.stride, p.ntaps, p.dtype, p.hi_off, p.wi_off, p.relu = 1, 9, e.dt, -1, -1, 1
+        p.osN, p.osH, p.osW = H * W * C_, W * C_, C_
+        p.out = 1
+        monkeypatch.delenv("DP_CONV_WS", raising=False)
+        assert (e.lib.dp_conv2d_kernel_class(C.byref(p)) == 6) == (N * H * W >= 256 and H >= (6 if C_ == 256 else 8)), (N, H, W)
+        monkeypatch.setenv("DP_WS_MIN_M", "1")
+        got = e.conv(layer, x, relu=True).t.clone()
+        monkeypatch.delenv("DP_WS_MIN_M")
+        monkeypatch.setenv("DP_CONV_WS", "0")
+        assert e.lib.dp_conv2d_kernel_class(C.byref(p)) != 6
+        want = e.conv(layer, x, relu=True).t
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), (N, H, W)
