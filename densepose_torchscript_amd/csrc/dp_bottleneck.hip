@@ -23,6 +23,7 @@
 // ragged tail are out-of-range buffer offsets (loads return 0, stores are dropped). One workgroup of 4 waves per CU.
 #include "dp_common.h"
 #include "dp_mma.h"
+#include "dp_policy.h"
 #include <stdlib.h>
 
 #ifndef DP_EXP
@@ -713,9 +714,8 @@ extern "C" int dp_bottleneck_tail_nhwc(const dp_bottleneck_params* p, dp_stream_
   a.t1_bytes = (unsigned)(M * 128); a.out_bytes = (unsigned)(M * 512); a.t1n_bytes = (unsigned)(M * 128);
   hipStream_t s = as_stream(stream);
   // two kernels for the same arithmetic: the strip walker (whole-line memory traffic, default whenever conv2 is the plain
-  // 3x3 / pad 1 it is written for) and the tile kernel (any tap offsets; DP_TAIL_KERNEL=tile selects it for A/B runs)
-  const char* ke = getenv("DP_TAIL_KERNEL");
-  const bool strip = !(ke && ke[0] == 't') && p->hi_off2 == -1 && p->wi_off2 == -1 && (long long)p->N * ((p->W + 15) / 16) * p->H < (1ll << 30);
+  // 3x3 / pad 1 it is written for) and the tile kernel (any tap offsets; policy key tail_kernel = 1 selects it for A/B runs)
+  const bool strip = dp_policy().tail_kernel == 0 && p->hi_off2 == -1 && p->wi_off2 == -1 && (long long)p->N * ((p->W + 15) / 16) * p->H < (1ll << 30);
   if (strip) {
     if (p->dtype == DP_BF16) return p->next_t1 ? launch_strip<uint16_t, true>(a, s) : launch_strip<uint16_t, false>(a, s);
     return p->next_t1 ? launch_strip<f16_t, true>(a, s) : launch_strip<f16_t, false>(a, s);

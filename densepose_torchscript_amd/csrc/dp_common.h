@@ -6,6 +6,7 @@
 #include <stdarg.h>
 
 #include "../../include/densepose_hip.h"
+#include "dp_policy.h"
 
 // ---- error reporting (host) -------------------------------------------------------------------
 extern thread_local char dp_err_buf[512];
@@ -128,6 +129,9 @@ int dp_conv_wsr_launch(const dp_conv_params* p, dp_stream_t stream);
 bool dp_conv_rows_ok(const dp_conv_params* p);
 bool dp_conv_rows2_ok(const dp_conv_params* p);     // its 32-pixel form (kernel class 8)
 int dp_conv_rows_launch(const dp_conv_params* p, dp_stream_t stream);
+// dp_conv_pw.hip: the weight-stationary pointwise kernel (K = 512 / 1024 / 2048 channels) behind dp_conv2d_nhwc (kernel class 9)
+bool dp_conv_pws_ok(const dp_conv_params* p);
+int dp_conv_pws_launch(const dp_conv_params* p, dp_stream_t stream);
 
 // Packed weight matrices are stored in 1 KiB TILES of 16 rows x 64 bytes of K (round 3): tile (rg, plane) of a matrix with
 // n_planes = Kpad * esize / 64 K planes sits at ((rg * n_planes) + plane) * 1024, row-major inside. One LDS-DMA wave instruction (16

@@ -31,7 +31,7 @@
 //     XCD and share its L2.
 #include "dp_common.h"
 #include "dp_mma.h"
-#include <stdlib.h>
+#include "dp_policy.h"
 #include <type_traits>
 
 namespace {
@@ -1075,7 +1075,7 @@ int launch_conv_stream(const ConvArgs& a, hipStream_t stream) {
 // the 256x256 ring tile is ~1.15x the 128x128 ring tile when both fill the chip, so the shape is picked by
 // wave-quantisation efficiency (workgroups / (CUs x resident workgroups per CU), rounded up to whole rounds);
 // short-K layers are HBM/latency bound and run on the generic kernel with 64-byte steps (4 workgroups per CU).
-enum { DP_CONV_K64 = 0, DP_CONV_K128 = 1, DP_CONV_RING256 = 2, DP_CONV_RING128 = 3, DP_CONV_RING256x128 = 4, DP_CONV_STREAM = 5, DP_CONV_WSR = 6, DP_CONV_ROWS = 7, DP_CONV_ROWS2 = 8 };
+enum { DP_CONV_K64 = 0, DP_CONV_K128 = 1, DP_CONV_RING256 = 2, DP_CONV_RING128 = 3, DP_CONV_RING256x128 = 4, DP_CONV_STREAM = 5, DP_CONV_WSR = 6, DP_CONV_ROWS = 7, DP_CONV_ROWS2 = 8, DP_CONV_PWS = 9 };
 
 static int num_cus() {
   static int n = 0;
@@ -1114,20 +1114,18 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
                          !p->out_f32 && lin_out && (lin_res || up_res) && M >= 4096 &&
                          // 32-bit buffer offsets, rows up to one grid stride of tiles past the end are addressed
                          (M + (1ll << 16)) * 2 * (p->Cin > p->osW ? p->Cin : (p->osW > p->rsW ? p->osW : p->rsW)) < (1ll << 31);
+  const DpPolicy& pol = dp_policy();
   if (p->Cout <= 64) {
-    const char* se64 = getenv("DP_CONV_STREAM");
-    if (stream_ok && !p->in2 && !getenv("DP_CONV_BIG") && !(se64 && atoi(se64) == 0)) return DP_CONV_STREAM;
+    if (stream_ok && !p->in2 && pol.conv_big < 0 && pol.conv_stream != 0) return DP_CONV_STREAM;
     return DP_CONV_K64;
   }
-  if (p->in2) {   // second source (K-concatenated pointwise layer): the LDS-ring kernels implement it (DP_CONV_BIG=2: the 128x128 one)
-    const char* f2 = getenv("DP_CONV_BIG");
+  if (p->in2) {   // second source (K-concatenated pointwise layer): the LDS-ring kernels implement it (conv_big = 2: the 128x128 one)
     if (!ring_ok) return -1;
-    if (big_ok && ((M + 127) / 128) * (p->Cout / 256) >= 128 && !(f2 && atoi(f2) == 2)) return DP_CONV_RING256;
+    if (big_ok && ((M + 127) / 128) * (p->Cout / 256) >= 128 && pol.conv_big != 2) return DP_CONV_RING256;
     return DP_CONV_RING128;
   }
-  const char* fe = getenv("DP_CONV_BIG");  // test/debug knob - 0: generic only, 1: 256x256 ring whenever legal, 2: 128x128 ring whenever legal, 5: streaming 1x1 whenever legal
-  if (fe) {
-    const int f = atoi(fe);
+  if (pol.conv_big >= 0) {   // test / calibration override - 0: generic only, 1: 256x256 ring whenever legal, 2: 128x128 ring whenever legal, 3: 256x128 ring, 5: streaming 1x1 whenever legal
+    const int f = (int)pol.conv_big;
     if (f == 5 && stream_ok) return DP_CONV_STREAM;
     if (f == 1 && big_ok) return DP_CONV_RING256;
     if (f == 2 && ring_ok) return DP_CONV_RING128;
@@ -1137,17 +1135,16 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   if (dp_conv_rows2_ok(p)) return DP_CONV_ROWS2;   // 3x3 with 512 input channels on maps whose width suits 32-pixel strips (DensePose head): dp_conv_rows.hip, third form
   if (dp_conv_rows_ok(p)) return DP_CONV_ROWS;     // 3x3 with 512 input channels (DensePose head, res5): row-streaming K-split weight-stationary kernel (dp_conv_rows.hip)
   if (dp_conv_wsr_ok(p)) return DP_CONV_WSR;       // 3x3 C -> C, C = 128 / 256: weights stationary in registers (dp_conv_ws.hip)
-  const char* se = getenv("DP_CONV_STREAM");   // A/B knob: 0 disables the streaming 1x1 kernel
-  if (stream_ok && !(se && atoi(se) == 0)) return DP_CONV_STREAM;
+  if (dp_conv_pws_ok(p)) return DP_CONV_PWS;       // 1x1 with K = 512 / 1024 / 2048: weights stationary in registers, pixels once through LDS (dp_conv_pw.hip)
+  if (stream_ok && pol.conv_stream != 0) return DP_CONV_STREAM;
   if (!ring_ok) return DP_CONV_K128;
   if ((long long)p->Kpad * es < 1024) return DP_CONV_K128;   // short K: see above
-  // Calibrated on the real layer shapes (scratch/conv_sweep.py, MI355X): the 256x256 ring tile wins whenever it has at
+  // Calibrated on the real layer shapes (tools/conv_sweep.py, MI355X): the 256x256 ring tile wins whenever it has at
   // least ~half a chip of tiles, even with a ragged last round (fewer resident workgroups run faster), except when the last
   // round is almost empty (p3-level 3x3: 525 tiles), where the 256x128 two-workgroup tile is ~7 % faster; small-M layers
   // (res5, p5, fully-connected: M <= 8400) need the 128x128 tile to occupy the chip at all.
-  const char* pe = getenv("DP_CONV_POLICY");  // A/B knob for the calibration runs
-  const int policy = pe ? atoi(pe) : 3;
-  if (policy == 0) {  // round-1 "a" policy: wave-quantisation estimate only
+#ifdef DP_EXPERIMENTS
+  if (pol.conv_policy == 0) {  // round-1 "a" policy: wave-quantisation estimate only
     const double cus = (double)num_cus();
     const double ts = (double)((M + 127) / 128) * ((p->Cout + 127) / 128);
     const double rs = ts / (2.0 * cus);
@@ -1160,17 +1157,18 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
     }
     return DP_CONV_RING128;
   }
-  if (big_ok) {
+  if (big_ok && pol.conv_policy == 1) {   // round-1 interim policy
     const long long t256 = ((M + 255) / 256) * (p->Cout / 256);
-    if (policy == 1) {   // round-1 interim policy, kept as an A/B knob
-      if (t256 >= 96 && (long long)p->Kpad * es >= 256 * 64) return DP_CONV_RING256;
-      if (t256 >= 132) {
-        const long long rem = t256 % num_cus();
-        if (t256 < 4ll * num_cus() && rem >= 1 && rem <= num_cus() / 6) return DP_CONV_RING256x128;
-        return DP_CONV_RING256;
-      }
-      return DP_CONV_RING128;
+    if (t256 >= 96 && (long long)p->Kpad * es >= 256 * 64) return DP_CONV_RING256;
+    if (t256 >= 132) {
+      const long long rem = t256 % num_cus();
+      if (t256 < 4ll * num_cus() && rem >= 1 && rem <= num_cus() / 6) return DP_CONV_RING256x128;
+      return DP_CONV_RING256;
     }
+    return DP_CONV_RING128;
+  }
+#endif
+  if (big_ok) {
     // the 256-cout kernel picks its own tile height (choose_ring256_tp); with 128-row tiles it beats the 128x128 kernel as
     // soon as it has about half a chip of them (res5 convs, fc2: 5-15 % faster at 132-252 tiles; p5-level 3x3 with 66: slower)
     const long long t128 = ((M + 127) / 128) * (p->Cout / 256);
@@ -1179,12 +1177,8 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   // Cout not a multiple of 256 on MANY pixels (the chart predictor's sub-pixel convolutions on hundreds of ROIs): the 256x128 tile with
   // two workgroups per CU puts four waves on a SIMD behind the same per-plane latency and wins 6 - 8 % from ~230 k pixels on
   // (512 -> 80 on N x 28 x 28: N = 300 / 400 / 600 / 800: 279 / 365 / 534 / 710 us against 304 / 392 / 569 / 767; N = 64: 102 against 76).
-  // Same K order as every ring tile: the choice may depend on the pixel count. DP_CONV_RING2_M: the line (0 = never).
-  {
-    const char* r2 = getenv("DP_CONV_RING2_M");
-    const long long line = r2 ? atoll(r2) : 230000;
-    if (line > 0 && M >= line && p->Cout > 64) return DP_CONV_RING256x128;
-  }
+  // Same K order as every ring tile: the choice may depend on the pixel count. conv_ring2_m: the line (0 = never).
+  if (pol.conv_ring2_m > 0 && M >= pol.conv_ring2_m && p->Cout > 64) return DP_CONV_RING256x128;
   return DP_CONV_RING128;
 }
 
@@ -1200,11 +1194,8 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
 // (0.206 ms on the 256x128 two-workgroup kernel -> 0.184 ms). The per-pixel arithmetic does not depend on the tile a pixel
 // lands in, so results stay bit-identical across batch sizes.
 static int choose_ring256_tp(const dp_conv_params* p, long long M) {
-  const char* fe = getenv("DP_CONV_TP");   // test / calibration knob
-  if (fe) {
-    const int f = atoi(fe);
-    if (f >= 4 && f <= 8) return f;
-  }
+  const int f = (int)dp_policy().conv_tp;   // test / calibration override
+  if (f >= 4 && f <= 8) return f;
   const long long tn = p->Cout / 256;
   const double cus = (double)num_cus();
   int best = 8;
@@ -1255,6 +1246,7 @@ extern "C" int dp_conv2d_tile_rows(const dp_conv_params* p) {
     case DP_CONV_WSR: return 16;
     case DP_CONV_ROWS: return 16;
     case DP_CONV_ROWS2: return 32;
+    case DP_CONV_PWS: return p->Cin == 2048 ? 16 : 32;
     default: return 128;
   }
 }
@@ -1340,6 +1332,7 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   }
   if (kc == DP_CONV_ROWS || kc == DP_CONV_ROWS2) return dp_conv_rows_launch(p, stream);
   if (kc == DP_CONV_WSR) return dp_conv_wsr_launch(p, stream);
+  if (kc == DP_CONV_PWS) return dp_conv_pws_launch(p, stream);
   if (p->post_res || p->post_mode)
     return dp_fail(DP_ERR_UNSUPPORTED, "dp_conv2d_nhwc: post_res (a tensor added after the activation) is implemented by the weight-stationary 3x3 kernel only "
                                         "(256 -> 256 channels, ReLU, 16-bit storage; post_mode 2 needs even H and W)");

@@ -390,6 +390,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_rows_kernel(const RowsArgs p) 
 #undef DP_STAMP
 }
 
+#ifdef DP_EXPERIMENTS   // measured slower (profiles/r4_rows_kernel_experiments.txt): built by `make exp` only
 // =====================================================================================================
 // The same arithmetic as a CHAIN with no workgroup barrier in the loop (round 4, second form). Phase stamps of the kernel above say a
 // step is 36 MFMAs per wave against ~1000 cycles of per-step fixed cost - the barrier that guards the staging buffer, the reduction of
@@ -634,6 +635,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_chain_kernel(const RowsArgs p)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy fetches behind the last step still target this workgroup's LDS
 }
+
+#endif  // DP_EXPERIMENTS
 
 // =====================================================================================================
 // Third form (round 4): 32 pixels per step, waves = 4 K quarters x 2 cout halves. The two forms above spend ~1000 cycles per step on
@@ -1054,6 +1057,7 @@ int launch_rows2(const RowsArgs& a, hipStream_t stream) {
   return dp_check_launch("conv3x3_rows2_kernel");
 }
 
+#ifdef DP_EXPERIMENTS
 template <typename T>
 int launch_chain(const RowsArgs& a, hipStream_t stream) {
   constexpr int lds = 8 * 4 * 3072 + 7 * 4 * 2048 + 2 * 2048 + 64;
@@ -1066,6 +1070,7 @@ int launch_chain(const RowsArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL((conv3x3_chain_kernel<T>), dim3(a.n_pg * a.n_slices), dim3(512), lds, stream, a);
   return dp_check_launch("conv3x3_chain_kernel");
 }
+#endif
 
 template <typename T, int CIN, int NCT>
 int launch_rows_r(const RowsArgs& a, hipStream_t stream) {
@@ -1145,23 +1150,20 @@ bool rows_common_ok(const dp_conv_params* p, int g) {
 }
 
 // the 32-pixel form: 512 input channels and a width whose strip groups are small (decided by the geometry alone: its summation order
-// differs from the 16-pixel form's). A/B knob DP_CONV_ROWS2=0.
+// differs from the 16-pixel form's). Policy key conv_rows2 = 0: never.
 bool rows2_ok(const dp_conv_params* p) {
-  const char* e = getenv("DP_CONV_ROWS2");
-  const char* e1 = getenv("DP_CONV_ROWS");
-  if ((e && atoi(e) == 0) || (e1 && atoi(e1) == 0)) return false;
+  const DpPolicy& pol = dp_policy();
+  if (pol.conv_rows2 == 0 || pol.conv_rows == 0) return false;
   if (p->W <= 0) return false;
   const int g = 32 / gcd_i(p->W, 32);
   // 512 channels: widths with strip groups of at most 8 images (28-wide ROI maps; res5's 42-wide maps - groups of 16 - stay on the 16-pixel
   // form). 256 channels (64 couts per workgroup): the layers with another cout count (the DensePose head's 256 -> 512 first layer: 93 us
   // against 105 on the LDS-ring kernel). On 256 -> 256 layers it measures the same as the weight-stationary kernel of dp_conv_ws.hip
   // (465 / 121 / 40 us against 461 / 121 / 39 at the three FPN levels), and the DeepLab head's device-sized 256 -> 256 layers gain nothing
-  // end to end (profiles/r4_rows_kernel_experiments.txt). DP_CONV_ROWS2_256: 0 never, 1 every 256-channel layer (A/B knobs).
-  const char* e2 = getenv("DP_CONV_ROWS2_256");
-  const int m256 = e2 ? atoi(e2) : -1;
+  // end to end (profiles/r4_rows_kernel_experiments.txt). Policy key conv_rows2_256: 0 never, 1 every 256-channel layer.
+  const int m256 = (int)pol.conv_rows2_256;
   const bool c256 = p->Cin == 256 && p->Cout % 64 == 0 && m256 != 0 && (m256 == 1 || p->Cout != 256);
-  const char* eg = getenv("DP_CONV_ROWS2_MAXG");       // experiments: largest strip group the 512-channel layers take (default 8)
-  const int maxg = eg ? atoi(eg) : 8;
+  const int maxg = (int)pol.conv_rows2_maxg;           // experiments: largest strip group the 512-channel layers take (default 8)
   const bool shape = (p->Cin == 512 && p->Cout % 32 == 0 && g <= maxg) || c256;
   return shape && rows2_width_ok(p->W) && rows_common_ok(p, g);
 }
@@ -1175,10 +1177,9 @@ bool dp_conv_rows_ok(const dp_conv_params* p) {
   // Default (mode 1): the 512-channel layers. Widths with small 32-pixel strip groups (the DensePose head's 28-wide ROI maps, with or
   // without a device-side count) take the 32-pixel form; the others (res5's conv2 at 42 columns) the 16-pixel form when the launch is
   // not sized on the device - for n_dev launches the 16-pixel form measured at par with the ring kernel
-  // (profiles/r4_rows_kernel_experiments.txt), and which kernel a call site takes must not depend on the batch. A/B knob DP_CONV_ROWS:
+  // (profiles/r4_rows_kernel_experiments.txt), and which kernel a call site takes must not depend on the batch. Policy key conv_rows:
   // 0 never, 2 the 16-pixel form also for n_dev launches and the 256 -> 512 layer.
-  const char* e = getenv("DP_CONV_ROWS");
-  const int mode = e ? atoi(e) : 1;
+  const int mode = (int)dp_policy().conv_rows;
   if (mode == 0) return false;
   if (mode != 2 && p->n_dev != nullptr) return false;
   const bool shape = (p->Cin == 512 && p->Cout % 32 == 0) || (p->Cin == 256 && p->Cout % 64 == 0 && mode == 2);
@@ -1189,7 +1190,7 @@ bool dp_conv_rows2_ok(const dp_conv_params* p) { return rows2_ok(p); }
 
 // 32-bit buffer offsets inside the kernels: a launch whose tensors exceed 2 GiB (thousands of ROI slots) goes as several launches over
 // chunks of whole strip groups - NOT to another kernel class: these kernels' summation order is their own, and an image's result
-// must not depend on how many others are in the batch. DP_ROWS_CHUNK_BYTES (tests) lowers the limit.
+// must not depend on how many others are in the batch. Policy key rows_chunk_bytes (tests) lowers the limit.
 int dp_conv_rows_launch(const dp_conv_params* p, dp_stream_t stream) {
   RowsArgs a;
   a.w = p->weight; a.bias = p->bias; a.n_dev = p->n_dev;
@@ -1206,13 +1207,13 @@ int dp_conv_rows_launch(const dp_conv_params* p, dp_stream_t stream) {
   a.dbg = nullptr;
   a.lockstep = 0;
   hipStream_t s = as_stream(stream);
-  const char* le = getenv("DP_CONV_ROWS2_LOCKSTEP");     // A/B knob: 1 = all eight waves on one schedule
-  if (two) a.lockstep = le && atoi(le) == 1;
-  const char* ce = getenv("DP_CONV_ROWS_CHAIN");         // A/B knob: 1 = the barrier-free chain form for the 512-channel layers
-  const bool chain = !two && p->Cin == 512 && ce && atoi(ce) == 1;
+  const DpPolicy& pol = dp_policy();
+  if (two) a.lockstep = pol.conv_rows2_lockstep == 1;    // policy key conv_rows2_lockstep: 1 = all eight waves on one schedule
+#ifdef DP_EXPERIMENTS
+  const bool chain = !two && p->Cin == 512 && pol.conv_rows_chain == 1;   // the barrier-free chain form for the 512-channel layers
+#endif
   const long long in_img = (long long)p->H * p->W * p->Cin * 2, out_img = (long long)p->H * p->W * p->osW * 2;
-  const char* lim_e = getenv("DP_ROWS_CHUNK_BYTES");
-  long long lim = lim_e ? atoll(lim_e) : (1ll << 31) - 1;
+  long long lim = pol.rows_chunk_bytes;
   if (lim < 1) lim = 1;
   long long per = lim / (in_img > out_img ? in_img : out_img);
   per = per / a.G * a.G;                                 // whole strip groups
@@ -1230,8 +1231,10 @@ int dp_conv_rows_launch(const dp_conv_params* p, dp_stream_t stream) {
     if (two) {
       if (p->Cin == 256) rc = p->dtype == DP_BF16 ? launch_rows2<uint16_t, 256>(a, s) : launch_rows2<f16_t, 256>(a, s);
       else rc = p->dtype == DP_BF16 ? launch_rows2<uint16_t, 512>(a, s) : launch_rows2<f16_t, 512>(a, s);
+#ifdef DP_EXPERIMENTS
     } else if (chain) {
       rc = p->dtype == DP_BF16 ? launch_chain<uint16_t>(a, s) : launch_chain<f16_t>(a, s);
+#endif
     } else {
       rc = p->dtype == DP_BF16 ? launch_rows<uint16_t>(a, p->Cin, s) : launch_rows<f16_t>(a, p->Cin, s);
     }

@@ -2,6 +2,7 @@
 // whole launch, input rows stream through an LDS ring. Behind dp_conv2d_nhwc (dp_conv.hip, kernel class 6).
 #include "dp_common.h"
 #include "dp_mma.h"
+#include "dp_policy.h"
 #include <stdlib.h>
 
 #ifndef DP_EXP
@@ -518,19 +519,17 @@ constexpr int kWsrRP128 = 4, kWsrRP256 = 3;
 
 // used by dp_conv2d_nhwc (dp_conv.hip): is this launch one of the C -> C 3x3 / pad 1 / stride 1 layers the kernel is written for?
 bool dp_conv_wsr_ok(const dp_conv_params* p) {
-  const char* e = getenv("DP_CONV_WS");    // A/B knob: 0 keeps these layers on the ring kernels, 4 only those that share the chip
-  const int mode = e ? atoi(e) : 1;
+  const int mode = (int)dp_policy().conv_ws;    // policy override: 0 keeps these layers on the ring kernels, 4 only those that share the chip
   if (mode == 0 || (mode == 4 && p->shared_chip)) return false;
   const long long M = (long long)p->N * p->H * p->W;
   const bool shape = (p->Cin == 128 && p->Cout == 128 && p->Cout_w == 128) || (p->Cin == 256 && p->Cout == 256 && p->Cout_w == 256);
   const int rp = p->Cin == 128 ? kWsrRP128 : kWsrRP256;
-  // fewest output pixels of a launch the kernel takes (DP_WS_MIN_M: calibration knob). Round 2 drew the line at 2048; measured again at
+  // fewest output pixels of a launch the kernel takes (policy key ws_min_m: calibration override). Round 2 drew the line at 2048; measured again at
   // batch 1 (one 25 x 42 / 13 x 21 map: the p5 / p6 levels of a single frame) the ring kernel needs 27 / 26 us for its 72 K planes, this
   // kernel 12 / 10 us - same bits either way, so the line only moves time
-  const char* em = getenv("DP_WS_MIN_M");
   // (launches with a post tensor keep the old line: whether the decoder's level sum is folded into the convolutions - a per-geometry
   // choice that moves rounding points - is decided by asking this function, and that choice stays what the parity tests pinned)
-  const long long min_m = p->post_res ? 2048 : (em ? atoll(em) : 256);
+  const long long min_m = p->post_res ? 2048 : dp_policy().ws_min_m;
   return (p->dtype == DP_BF16 || p->dtype == DP_F16) && !p->n_dev && shape && p->ntaps == 9 && p->Kpad == 9 * p->Cin && p->stride == 1 &&
          (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == -1 && p->wi_off == -1 && p->H == p->Ho && p->W == p->Wo &&
          !p->residual && !p->out_f32 && !p->head_out && p->out && p->osW == p->Cout && p->osH == (long long)p->W * p->Cout &&
@@ -556,11 +555,9 @@ int dp_conv_wsr_launch(const dp_conv_params* p, dp_stream_t stream) {
     // beside the proposal top-k / NMS chain): one workgroup per CU on all but one group of CUs, which stay free for that chain -
     // its single-wave workgroups otherwise wait for a workgroup of this launch to END before they get a CU (every CU's LDS and
     // registers are taken), which stretched the chain 2 - 3x (profiles/r3_timeline_*.txt). A/B knobs for all three cases.
-    const char* es = getenv("DP_WS_OVER_SHARED");
-    const char* ea = getenv("DP_WS_OVER_ALONE");
-    const char* er = getenv("DP_WS_RESERVE");
-    if (p->shared_chip == 2) a.over = -(er ? atoi(er) : 1);
-    else a.over = p->shared_chip ? (es ? atoi(es) : 2) : (ea ? atoi(ea) : 1);
+    const DpPolicy& pol = dp_policy();
+    if (p->shared_chip == 2) a.over = -(int)pol.ws_reserve;
+    else a.over = (int)(p->shared_chip ? pol.ws_over_shared : pol.ws_over_alone);
     if (a.over == 0) a.over = 1;
   }
   a.in_bytes = (unsigned)((long long)p->N * p->H * p->W * p->Cin * 2);

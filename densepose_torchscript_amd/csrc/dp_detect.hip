@@ -1057,10 +1057,10 @@ extern "C" int dp_roi_align_nhwc(const dp_roi_align_params* p, dp_stream_t strea
   const int bins_per_block = 2048 / C8 > 0 ? 2048 / C8 : 1;
   a.items_per_block = bins_per_block * C8;
   const dim3 grid((p->P * p->P + bins_per_block - 1) / bins_per_block, p->max_rois, p->n_img), block(256);
-  // DP_ROI_TAB=0: the per-sample kernel for every sampling ratio (A/B: 288 -> 193 us for the box head's 8 x 1000 ROIs, + 2.3 % images/s).
+  // policy key roi_tab = 0: the per-sample kernel for every sampling ratio (A/B: 288 -> 193 us for the box head's 8 x 1000 ROIs, + 2.3 % images/s).
   // Pinning image i's ROIs to XCD i % 8 on top (one L2 per feature map) cut the bytes fetched beyond L2 by 7 - 15 % and the time by
   // nothing: the kernel is bound by L2 -> L1 requests (3.2 GB of corner reads per launch), not by what L2 misses.
-  static const bool tab_mode = !(getenv("DP_ROI_TAB") && atoi(getenv("DP_ROI_TAB")) == 0);
+  const bool tab_mode = dp_policy().roi_tab != 0;
   if (tab_mode && p->sampling == 2 && p->P * 2 <= kRoiTab) {
     if (p->dtype == DP_F32) hipLaunchKernelGGL((roi_align_tab_kernel<float, 2>), grid, block, 0, s, a);
     else if (p->dtype == DP_BF16) hipLaunchKernelGGL((roi_align_tab_kernel<uint16_t, 2>), grid, block, 0, s, a);

@@ -730,12 +730,11 @@ extern "C" int dp_iuv_upsample_split(const dp_iuv_params* p, dp_stream_t stream)
   DP_REQUIRE(2 * p->Ws <= 256, "dp_iuv_upsample_split: output rows wider than 256");
   int xslots = 64;   // power of two >= the output width: a channel lane covers whole waves
   while (xslots < 2 * p->Ws) xslots *= 2;
-  // four outputs per thread and 16-byte stores when every output row starts on a 16-byte boundary (A/B knob DP_IUV_QUAD=0);
+  // four outputs per thread and 16-byte stores when every output row starts on a 16-byte boundary (policy key iuv_quad = 0: A/B);
   // passed as a negative slot count = - (power of two >= output width / 4)
-  const char* qe = getenv("DP_IUV_QUAD");
   const bool al16 = ((reinterpret_cast<uintptr_t>(p->coarse) | reinterpret_cast<uintptr_t>(p->fine) | reinterpret_cast<uintptr_t>(p->u) |
                       reinterpret_cast<uintptr_t>(p->v)) & 15) == 0;
-  if ((2 * p->Ws) % 4 == 0 && al16 && !(qe && atoi(qe) == 0)) {
+  if ((2 * p->Ws) % 4 == 0 && al16 && dp_policy().iuv_quad != 0) {
     int qs = 16;
     while (qs < (2 * p->Ws) / 4) qs *= 2;
     xslots = -qs;
@@ -785,8 +784,7 @@ extern "C" int dp_groupnorm_relu_nhwc(const dp_groupnorm_params* p, dp_stream_t 
     const int es = p->dtype == DP_F32 ? 4 : 2, ve = 16 / es, cg = p->C / p->groups;
     const long long nv = (long long)p->HW * (cg / ve);
     const bool vec_ok = cg % ve == 0 && p->c_stride % ve == 0 && p->c_off % ve == 0 && (reinterpret_cast<uintptr_t>(p->x) & 15) == 0;
-    static int reg_on = -1;     // DP_GN_REG=0: A/B knob (the element-wise three-sweep kernel), 1: one group per workgroup only
-    if (reg_on < 0) { const char* e = getenv("DP_GN_REG"); reg_on = e ? atoi(e) : 2; }
+    const int reg_on = (int)dp_policy().gn_reg;     // policy key gn_reg: 0 = the element-wise three-sweep kernel, 1 = one group per workgroup only
     // whole-line form: the groups sharing a 128-byte line go to one workgroup
     const int line_groups = (cg * es <= 128 && 128 % (cg * es) == 0) ? 128 / (cg * es) : 0;
     if (reg_on >= 2 && vec_ok && line_groups >= 1 && p->groups % line_groups == 0 && (p->c_stride * es) % 128 == 0 && (p->c_off * es) % 128 == 0 &&

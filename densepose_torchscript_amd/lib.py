@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("DP_HIP_LIB") or os.path.join(_HERE, "libdensepose_hip
 CSRC = os.path.join(_HERE, "csrc")
 
 DP_F32, DP_BF16, DP_F16 = 0, 1, 2
-ABI_VERSION = 5   # == DP_ABI_VERSION of include/densepose_hip.h (bumped whenever a params struct or the symbol set changes)
+ABI_VERSION = 6   # == DP_ABI_VERSION of include/densepose_hip.h (bumped whenever a params struct or the symbol set changes)
 
 # user-facing dtype names -> (enum, element size)
 DTYPES = {"fp32": DP_F32, "float32": DP_F32, "bf16": DP_BF16, "bfloat16": DP_BF16, "fp16": DP_F16, "float16": DP_F16, "half": DP_F16}
@@ -166,6 +166,11 @@ SYMBOLS = {
     "dp_resize_preprocess_u8_batch": (c_int, [C.POINTER(ResizeParams), C.POINTER(c_void_p), c_int, C.POINTER(PreprocessParams), c_void_p]),
     "dp_preprocess_u8_frames": (c_int, [C.POINTER(PreprocessParams), C.POINTER(c_void_p), c_int, c_void_p]),
     "dp_iuv_extract": (c_int, [C.POINTER(IuvExtractParams), c_void_p]),
+    "dp_set_policy": (c_int, [C.c_char_p, c_i64]),
+    "dp_get_policy": (c_int, [C.c_char_p, C.POINTER(c_i64)]),
+    "dp_reset_policy": (None, []),
+    "dp_policy_num_keys": (c_int, []),
+    "dp_policy_key": (C.c_char_p, [c_int]),
 }
 
 
@@ -235,7 +240,59 @@ def load():
     if lib.dp_abi_version() != ABI_VERSION:
         raise DensePoseHipError("ABI version mismatch: library %d, binding %d" % (lib.dp_abi_version(), ABI_VERSION))
     _lib = lib
+    _apply_env_policy(lib)
     return lib
+
+
+def policy_keys():
+    lib = load()
+    return [lib.dp_policy_key(i).decode() for i in range(lib.dp_policy_num_keys())]
+
+
+def set_policy(key, value):
+    """Kernel-policy override (include/densepose_hip.h dp_set_policy): tests pin a kernel class, tools A/B a schedule."""
+    check(load().dp_set_policy(key.encode(), int(value)), "dp_set_policy(%s)" % key)
+
+
+def get_policy(key):
+    v = c_i64(0)
+    check(load().dp_get_policy(key.encode(), C.byref(v)), "dp_get_policy(%s)" % key)
+    return v.value
+
+
+def reset_policy():
+    load().dp_reset_policy()
+
+
+class policy:
+    """with policy(conv_big=1, conv_tp=6): ...   - overrides for the duration of the block, previous values restored afterwards."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = get_policy(k)
+            set_policy(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_policy(k, v)
+        return False
+
+
+def _apply_env_policy(lib):
+    """The library itself never reads the environment. For the command-line tools (tools/*.sh A/B runs: `DP_CONV_WS=0 python bench.py`)
+    the HOST side applies DP_<KEY> variables to the policy table once, when the library is loaded."""
+    for i in range(lib.dp_policy_num_keys()):
+        key = lib.dp_policy_key(i).decode()
+        v = os.environ.get("DP_" + key.upper())
+        if v is not None and v.strip() != "":
+            if key == "tail_kernel" and not v.lstrip("-").isdigit():
+                v = "1" if v.startswith("t") else "0"     # historical spelling: DP_TAIL_KERNEL=tile
+            if lib.dp_set_policy(key.encode(), int(v)) != 0:
+                raise DensePoseHipError("bad policy override DP_%s=%s" % (key.upper(), v))
 
 
 def check(rc, what=""):

@@ -37,10 +37,24 @@ enum dp_status {
   DP_ERR_LAUNCH = -3        /* hipGetLastError() after launch */
 };
 
-#define DP_ABI_VERSION 5
+#define DP_ABI_VERSION 6
 int dp_abi_version(void);
 /* human-readable reason of the last non-zero return on this thread */
 const char* dp_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel-policy overrides (ABI 6). The reference has no counterpart: ATen picks its kernels by itself
+ * (wrappers.py:105 F.conv2d). Here the choice of a kernel fixes a layer's summation order, hence its bits, so it must
+ * not depend on anything but the layer and this table. NO entry point reads the process environment; the table holds
+ * the defaults of csrc/dp_policy.h until a caller changes it:
+ *   tests pin a kernel class ("conv_big", "conv_ws", "conv_rows", "conv_pws" ...), tools/ A/B a schedule.
+ * Process-wide, not thread-safe against concurrent launches (set it before launching). Unknown key: DP_ERR_BAD_ARG.
+ * ------------------------------------------------------------------------------------------- */
+int dp_set_policy(const char* key, int64_t value);
+int dp_get_policy(const char* key, int64_t* value);
+void dp_reset_policy(void);              /* every key back to its default */
+int dp_policy_num_keys(void);
+const char* dp_policy_key(int index);    /* NULL past the end */
 
 /* ---------------------------------------------------------------------------------------------
  * K2  rcnn.py:162,180  (x - pixel_mean) / pixel_std ; F.pad(right/bottom, 0) ; + NCHW->NHWC, C 3->8
@@ -150,7 +164,10 @@ int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
  * input channels on maps whose width gives strip groups of at most 8 images, e.g. the DensePose head's 28-wide ROI maps, with or
  * without n_dev, and the 256 -> 512 first layer of that head on a 64-cout instance; chosen by the geometry alone, its summation order
  * differs from class 7's; classes 7 / 8 cut a launch whose tensors exceed 2 GiB into several launches over chunks of whole strip groups
- * instead of handing it to another class) - profiling / roofline bookkeeping only */
+ * instead of handing it to another class), 9 = weight-stationary pointwise kernel (1 tap, stride 1, K = 512 / 1024 / 2048 channels:
+ * conv1 of res4 / res5 and conv3 of res5 resnet.py:189-205, the FPN laterals fpn.py:140-157, fc2 box_head.py:71-73; a 256 KiB slice
+ * of the weights in registers, pixels once through LDS, K slices added in a fixed order of its own - chosen by the channel counts
+ * alone) - profiling / roofline bookkeeping only */
 int dp_conv2d_kernel_class(const dp_conv_params* p);
 /* pixel rows of the tile dp_conv2d_nhwc will use for these parameters (the 256-cout ring kernel picks 128 .. 256 rows in
  * steps of 32 to fit the launch into whole rounds of the chip) - profiling / roofline bookkeeping only */

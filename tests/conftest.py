@@ -43,3 +43,29 @@ ALL_GOLDENS = ["tiny_r50_s1x_a", "tiny_r50_s1x_b", "tiny_r50_legacy", "tiny_r101
 def gpu_available():
     import torch
     return torch.cuda.is_available()
+
+
+class _Policy:
+    """Kernel-policy overrides of the HIP library for one test (dp_set_policy; the library never reads the environment)."""
+
+    def __init__(self):
+        from densepose_torchscript_amd import lib
+        self.lib = lib
+        self.defaults = {}
+
+    def set(self, key, value):
+        if key not in self.defaults:
+            self.defaults[key] = self.lib.get_policy(key)
+        self.lib.set_policy(key, int(value))
+
+    def default(self, key):
+        if key in self.defaults:
+            self.lib.set_policy(key, self.defaults[key])
+
+
+@pytest.fixture
+def policy():
+    pol = _Policy()
+    yield pol
+    for k, v in pol.defaults.items():
+        pol.lib.set_policy(k, v)

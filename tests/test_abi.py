@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in _declared_symbols():
         assert hasattr(raw, name), name
     lib = built.load()
-    assert lib.dp_abi_version() == 5 == built.ABI_VERSION
+    assert lib.dp_abi_version() == 6 == built.ABI_VERSION
 
 
 def test_argument_validation_without_gpu(built):
@@ -117,3 +117,34 @@ def test_no_kernel_uses_scratch(built, tmp_path):
         n_kernels += len(sizes)
         assert sizes and all(int(s) == 0 for s in sizes), (o.name, [(n, s) for n, s in zip(names, sizes) if int(s)])
     assert n_kernels > 100     # every template instance of every kernel was looked at
+
+
+def test_policy_table_and_no_environment_reads(built, monkeypatch):
+    """Kernel choice is a property of the layer and of the policy table (dp_set_policy), never of the process environment: the
+    library's sources contain no getenv, an environment variable set AFTER the load changes nothing, the table does."""
+    import glob
+    import os
+    for f in glob.glob(os.path.join(built.CSRC, "*")):
+        if f.endswith((".hip", ".cpp", ".h")):
+            assert "getenv" not in open(f).read(), f
+    lib = built.load()
+    built.reset_policy()
+    keys = built.policy_keys()
+    assert "conv_pws" in keys and "conv_big" in keys and len(keys) == len(set(keys))
+    assert lib.dp_set_policy(b"no_such_key", 1) == -1
+    p = built.ConvParams()       # res4's conv1 (resnet.py:192-193): 1024 -> 256 pointwise on 8 x 50 x 84 pixels, bf16
+    p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = 8, 50, 84, 1024, 50, 84, 256, 256, 1024
+    p.stride, p.ntaps, p.dtype = 1, 1, built.DP_BF16
+    p.osN, p.osH, p.osW = 50 * 84 * 256, 84 * 256, 256
+    p.in_, p.weight, p.out = 4096, 4096, 4096      # aligned placeholders: the class query looks at NULL / alignment only
+    assert lib.dp_conv2d_kernel_class(ctypes.byref(p)) == 9
+    p.N = 1                                        # the class of a layer does not depend on the batch
+    assert lib.dp_conv2d_kernel_class(ctypes.byref(p)) == 9
+    monkeypatch.setenv("DP_CONV_PWS", "0")         # the environment is not consulted after the load ...
+    assert lib.dp_conv2d_kernel_class(ctypes.byref(p)) == 9
+    with built.policy(conv_pws=0):                 # ... the table is
+        assert built.get_policy("conv_pws") == 0
+        assert lib.dp_conv2d_kernel_class(ctypes.byref(p)) in (2, 3)
+    assert lib.dp_conv2d_kernel_class(ctypes.byref(p)) == 9
+    p.dtype = built.DP_F32                         # fp32 parity mode stays on the exact-fp32 kernels
+    assert lib.dp_conv2d_kernel_class(ctypes.byref(p)) != 9

@@ -733,7 +733,7 @@ def test_host_resident_frames_equal_device_resident_frames():
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_fused_launches_equal_layer_by_layer_end_to_end(dtype, monkeypatch):
+def test_fused_launches_equal_layer_by_layer_end_to_end(dtype, policy):
     """The fused kernels only exist for 16-bit storage, so the fp32 goldens never run them: end to end in the throughput dtypes
     the default engine (stem + pool fused, res2 tails fused, RPN heads in the conv epilogue, weight-stationary 3x3) must equal,
     bit for bit, an engine with every fusion off and the 3x3 layers on the ring kernels."""
@@ -747,7 +747,7 @@ def test_fused_launches_equal_layer_by_layer_end_to_end(dtype, monkeypatch):
     want = fused.predict_batch(imgs)
     torch.cuda.synchronize()
     want = [{k: v.cpu() for k, v in r.items()} for r in want]
-    monkeypatch.setenv("DP_CONV_WS", "0")
+    policy.set("conv_ws", "0")
     plain = DensePosePredictor(cfg, state, dtype=dtype, resize="device")
     plain.engine.fuse_stem_pool = plain.engine.fuse_bottleneck = plain.engine.fuse_rpn_head = False
     got = plain.predict_batch(imgs)

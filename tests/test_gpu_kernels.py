@@ -61,17 +61,17 @@ BIG_CASES = [
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("tp", ["4", "5", "6", "7"])   # tile heights 128 .. 224 of the 256-cout ring kernel (8 = default, above)
 @pytest.mark.parametrize("case", BIG_CASES[:6])
-def test_conv2d_ring_tile_heights(eng, dt, case, tp, monkeypatch):
-    monkeypatch.setenv("DP_CONV_BIG", "1")
-    monkeypatch.setenv("DP_CONV_TP", tp)
+def test_conv2d_ring_tile_heights(eng, dt, case, tp, policy):
+    policy.set("conv_big", "1")
+    policy.set("conv_tp", tp)
     test_conv2d_matches_torch(eng, dt, case)
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("force", ["1", "2", "3"])   # 1: 256x256 ring kernel, 2: 128x128 ring kernel, 3: 256x128 two-WG ring kernel
 @pytest.mark.parametrize("case", BIG_CASES)
-def test_conv2d_ring_kernels(eng, dt, case, force, monkeypatch):
-    monkeypatch.setenv("DP_CONV_BIG", force)
+def test_conv2d_ring_kernels(eng, dt, case, force, policy):
+    policy.set("conv_big", force)
     test_conv2d_matches_torch(eng, dt, case)
 
 
@@ -96,10 +96,10 @@ def _random_conv_cases(n, seed):
 
 @pytest.mark.parametrize("force", [None, "1", "2", "3", "5"])
 @pytest.mark.parametrize("dt", ["bf16", "fp32"])
-def test_conv2d_random_shapes(eng, dt, force, monkeypatch):
+def test_conv2d_random_shapes(eng, dt, force, policy):
     """Every kernel class (forced where it is legal for the shape, else the generic fallback) on 24 seeded random shapes."""
     if force is not None:
-        monkeypatch.setenv("DP_CONV_BIG", force)
+        policy.set("conv_big", force)
     for case in _random_conv_cases(24, 1234 + (0 if force is None else int(force))):
         test_conv2d_matches_torch(eng, dt, case)
 
@@ -117,7 +117,7 @@ STREAM_CASES = [
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("shape", [(2, 256, 48, 64, 256), (3, 64, 40, 38, 256), (1, 128, 70, 62, 512)])
-def test_conv2d_stream_kernel_upsampled_residual(eng, dt, shape, monkeypatch):
+def test_conv2d_stream_kernel_upsampled_residual(eng, dt, shape, policy):
     """FPN lateral + top-down add (fpn.py:150-155: lateral 1x1 conv + F.interpolate(top, x2, nearest)) on the streaming 1x1
     kernel: the residual is the half-size map read at (ho >> 1, wo >> 1). Same result as the generic kernel bit for bit."""
     from densepose_torchscript_amd import lib as L
@@ -133,9 +133,9 @@ def test_conv2d_stream_kernel_upsampled_residual(eng, dt, shape, monkeypatch):
     layer = conv_from_oihw("lat", w.numpy(), b.numpy(), Cin, 1, 0, 1, e.dt, e.device)
     xa = Act(_nhwc(x, Cin, e.tdt, e.device), N, H, W, Cin)
     ta = Act(_nhwc(top, Cout, e.tdt, e.device), N, H // 2, W // 2, Cout)
-    monkeypatch.setenv("DP_CONV_STREAM", "0")
+    policy.set("conv_stream", "0")
     want = e.conv(layer, xa, residual=ta, rshift=1)
-    monkeypatch.delenv("DP_CONV_STREAM")
+    policy.default("conv_stream")
     p = L.ConvParams()
     p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, Cin, H, W, Cout, Cout, Cin
     p.stride, p.ntaps, p.dtype, p.out_f32, p.rshift = 1, 1, e.dt, 0, 1
@@ -154,9 +154,9 @@ def test_conv2d_stream_kernel_upsampled_residual(eng, dt, shape, monkeypatch):
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", STREAM_CASES)
-def test_conv2d_stream_kernel(eng, dt, case, monkeypatch):
+def test_conv2d_stream_kernel(eng, dt, case, policy):
     from densepose_torchscript_amd import lib as L
-    monkeypatch.setenv("DP_CONV_BIG", "5")
+    policy.set("conv_big", "5")
     orig = eng[dt].lib.dp_conv2d_kernel_class
     test_conv2d_matches_torch(eng, dt, case)
     # the storage-type launch of this shape really is the streaming kernel (class 5)
@@ -166,6 +166,77 @@ def test_conv2d_stream_kernel(eng, dt, case, monkeypatch):
     p.stride, p.ntaps, p.dtype, p.out_f32 = 1, 1, eng[dt].dt, 0
     p.osN, p.osH, p.osW = H * W * Cout, W * Cout, Cout
     assert orig(C.byref(p)) == 5
+
+
+PWS_CASES = [
+    # N, Cin, H, W, Cout, relu, residual (None / "lin" / "up"): the weight-stationary pointwise kernel (dp_conv_pw.hip, kernel class 9)
+    (2, 1024, 50, 84, 256, True, None),      # res4 conv1: 2 cout slices x 128 pixel groups, 8400 pixels = 2 - 3 steps per workgroup
+    (3, 1024, 13, 21, 256, True, None),      # fewer steps than pixel groups, ragged last step (819 pixels)
+    (2, 1024, 26, 40, 256, False, "up"),     # fpn_lateral4: top-down map through the nearest x2 up-sampling
+    (1, 1024, 1, 1000, 1024, True, None),    # fc2 (box_head.py:71-73): rows of a [1000, 1024] matrix, 8 cout slices
+    (2, 512, 25, 42, 2048, True, "lin"),     # res5 conv3 + residual: no K split, 8 cout slices
+    (1, 512, 37, 45, 256, False, "up"),      # fpn_lateral3 geometry class: one cout slice (odd sizes: "up" needs even ones -> below)
+    (2, 2048, 25, 42, 512, True, None),      # res5 conv1: four K slices, 16-pixel steps
+    (1, 2048, 26, 42, 256, False, None),     # fpn_lateral5
+    (3, 2048, 7, 9, 64, False, "lin"),       # one cout slice of 64, 189 pixels
+]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", PWS_CASES)
+def test_conv1x1_weight_stationary_pointwise(eng, dt, case, policy):
+    """conv1 / conv3 of res4 / res5 (resnet.py:189-205), the FPN laterals (fpn.py:140-157) and fc2 on the weight-stationary pointwise
+    kernel: against torch in fp64 on operands rounded to the storage type, against the LDS-ring kernels (same products, another
+    summation order), and every image alone against the image inside the batch, bit for bit (the K slices are added in a fixed order)."""
+    from densepose_torchscript_amd import lib as L
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    e = eng[dt]
+    N, Cin, H, W, Cout, relu, rmode = case
+    if rmode == "up" and (H % 2 or W % 2):
+        H, W = H + H % 2, W + W % 2
+    g = torch.Generator().manual_seed(Cin + Cout + N * 1000 + H * 10 + W)
+    x = _round(torch.randn((N, Cin, H, W), generator=g), dt)
+    w = _round(torch.randn((Cout, Cin, 1, 1), generator=g) * (1.0 / Cin) ** 0.5, dt)
+    b = torch.randn((Cout,), generator=g) * 0.3
+    layer = conv_from_oihw("pw", w.numpy(), b.numpy(), Cin, 1, 0, 1, e.dt, e.device)
+    xa = Act(_nhwc(x, Cin, e.tdt, e.device), N, H, W, Cin)
+    ra, rshift, rref = None, 0, 0.0
+    if rmode == "lin":
+        r = _round(torch.randn((N, Cout, H, W), generator=g), dt)
+        ra, rref = Act(_nhwc(r, Cout, e.tdt, e.device), N, H, W, Cout), r.double()
+    elif rmode == "up":
+        r = _round(torch.randn((N, Cout, H // 2, W // 2), generator=g), dt)
+        ra, rshift = Act(_nhwc(r, Cout, e.tdt, e.device), N, H // 2, W // 2, Cout), 1
+        rref = F.interpolate(r.double(), scale_factor=2.0, mode="nearest")
+    p = L.ConvParams()
+    p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, Cin, H, W, Cout, layer.cout_w, Cin
+    p.stride, p.ntaps, p.dtype, p.rshift = 1, 1, e.dt, rshift
+    p.osN, p.osH, p.osW = H * W * Cout, W * Cout, Cout
+    p.in_, p.weight, p.out = xa.t.data_ptr(), layer.weight.data_ptr(), xa.t.data_ptr()
+    if ra is not None:
+        p.residual = ra.t.data_ptr()
+        p.rsN, p.rsH, p.rsW = ra.H * ra.W * Cout, ra.W * Cout, Cout
+    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 9
+    got = e.conv(layer, xa, relu=relu, residual=ra, rshift=rshift)
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.double(), w.double(), b.double()) + rref
+    ref = F.relu(ref) if relu else ref
+    ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    gd = got.t.float().cpu().permute(0, 3, 1, 2).double()
+    assert bool(((gd - ref).abs() <= ulp * ref.abs() + 2e-3).all()), float((gd - ref).abs().max())
+    # every image alone == the image inside the batch, bit for bit
+    for i in sorted({0, N - 1}):
+        ri = None if ra is None else Act(ra.t[i:i + 1].contiguous(), 1, ra.H, ra.W, Cout)
+        one = e.conv(layer, Act(xa.t[i:i + 1].contiguous(), 1, H, W, Cin), relu=relu, residual=ri, rshift=rshift)
+        assert torch.equal(one.t[0], got.t[i]), i
+    # the ring kernels on the same operands: equal up to the summation order
+    policy.set("conv_pws", 0)
+    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) != 9
+    want = e.conv(layer, xa, relu=relu, residual=ra, rshift=rshift)
+    torch.cuda.synchronize()
+    d = (want.t.float() - got.t.float()).abs()
+    assert bool((d <= 2 * ulp * want.t.float().abs() + 1e-3).all()), float(d.max())
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
@@ -361,7 +432,7 @@ def test_paired_preprocess_and_stem(eng, dt, shape):
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("tp", [None, "4", "5", "6", "7"])          # every tile height of the 256-cout ring kernel
 @pytest.mark.parametrize("shape", [(1, 40, 56), (2, 13, 21), (3, 9, 11), (1, 50, 84)])
-def test_conv_with_fused_rpn_head(eng, dt, tp, shape, monkeypatch):
+def test_conv_with_fused_rpn_head(eng, dt, tp, shape, policy):
     """RPN head (rpn.py:168-171: 3x3 conv + ReLU, then the 1x1 objectness / anchor-delta convolutions) in ONE launch: the head is
     applied in the ring kernel's epilogue and the 256-channel hidden tensor is never written. BIT-identical to the two-launch
     form (same rounded hidden tensor, head accumulated over the K planes in the same order - the four 64-channel blocks are
@@ -369,9 +440,9 @@ def test_conv_with_fused_rpn_head(eng, dt, tp, shape, monkeypatch):
     from densepose_torchscript_amd.engine import Act
     from densepose_torchscript_amd.pack import conv_from_oihw
     e = eng[dt]
-    monkeypatch.setenv("DP_CONV_BIG", "1")       # the 256-cout ring kernel whatever the tile count
+    policy.set("conv_big", "1")       # the 256-cout ring kernel whatever the tile count
     if tp:
-        monkeypatch.setenv("DP_CONV_TP", tp)
+        policy.set("conv_tp", tp)
     N, H, W = shape
     g = torch.Generator().manual_seed(N * 100 + H + W)
     x = _round(torch.randn((N, 256, H, W), generator=g), dt)
@@ -449,7 +520,7 @@ def test_stem_pool_fused_equals_conv_then_pool(eng, dt, shape):
                                    (128, 2, 64, 35, False), (128, 1, 47, 130, True), (256, 1, 50, 84, True), (256, 2, 37, 45, False),
                                    (256, 3, 25, 42, True), (256, 1, 100, 168, False), (256, 2, 64, 35, True), (256, 1, 47, 130, True),
                                    (256, 8, 13, 32, True), (128, 16, 9, 17, False)])
-def test_conv3x3_weight_stationary_equals_ring_kernel(eng, dt, shape, monkeypatch):
+def test_conv3x3_weight_stationary_equals_ring_kernel(eng, dt, shape, policy):
     """The weight-stationary 3x3 kernels (weights in registers, pixel rows in an LDS ring; C -> C channels, C = 128: res3 conv2,
     resnet.py:195-197; C = 256: res4 conv2, FPN outputs, decoder) against the LDS-ring kernel they replace - bit-identical
     (same K order, for C = 256 chained through two waves) - and torch in fp64. Odd heights (a ragged last step), widths that are
@@ -459,7 +530,7 @@ def test_conv3x3_weight_stationary_equals_ring_kernel(eng, dt, shape, monkeypatc
     from densepose_torchscript_amd.pack import conv_from_oihw
     e = eng[dt]
     Cc, N, H, W, relu = shape
-    monkeypatch.delenv("DP_CONV_WS", raising=False)
+    policy.default("conv_ws")
     g = torch.Generator().manual_seed(N * 1000 + H * 10 + W + Cc)
     x = _round(torch.randn((N, Cc, H, W), generator=g), dt)
     w = _round(torch.randn((Cc, Cc, 3, 3), generator=g) * (1.0 / (9 * Cc)) ** 0.5, dt)
@@ -482,7 +553,7 @@ def test_conv3x3_weight_stationary_equals_ring_kernel(eng, dt, shape, monkeypatc
     finally:
         e._shared_chip = False
     assert torch.equal(got.t, hinted.t)
-    monkeypatch.setenv("DP_CONV_WS", "0")
+    policy.set("conv_ws", "0")
     assert e.lib.dp_conv2d_kernel_class(C.byref(p)) != 6
     want = e.conv(layer, xa, relu=relu)
     torch.cuda.synchronize()
@@ -536,12 +607,13 @@ def _rows2_width_ok(W, max_group=8):
     return True
 
 
-# rows: the 16-pixel form; chain: its barrier-free variant (DP_CONV_ROWS_CHAIN=1, an A/B knob); rows2: the 32-pixel form (4 K quarters x
-# 2 cout halves) that the default policy picks where the width allows; rows2_lockstep: the same on one schedule for all waves (A/B knob)
-@pytest.mark.parametrize("variant", ["rows", "chain", "rows2", "rows2_lockstep"])
+# rows: the 16-pixel form; rows2: the 32-pixel form (4 K quarters x 2 cout halves) that the default policy picks where the width allows;
+# rows2_lockstep: the same on one schedule for all waves (policy key conv_rows2_lockstep). (The barrier-free chain variant of round 4
+# measured slower and is compiled into `make exp` builds only.)
+@pytest.mark.parametrize("variant", ["rows", "rows2", "rows2_lockstep"])
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", ROWS_CASES)
-def test_conv3x3_rows_kernel(eng, dt, case, variant, monkeypatch):
+def test_conv3x3_rows_kernel(eng, dt, case, variant, policy):
     """The row-streaming K-split weight-stationary 3x3 kernel (dp_conv_rows.hip, kernel class 7: the DensePose head's
     body_conv_fcn1..8, v1convx.py:44-59 / deeplab.py:64-74, and res5's conv2, resnet.py:195-197) against torch in fp64 on operands
     rounded to the storage type, against the LDS-ring kernel (same products, another summation order), and against itself image by
@@ -553,22 +625,17 @@ def test_conv3x3_rows_kernel(eng, dt, case, variant, monkeypatch):
     e = eng[dt]
     Ci, Co, N, H, W, live, relu = case
     two_ok = (Ci == 512 and _rows2_width_ok(W)) or (Ci == 256 and _rows2_width_ok(W, 1 << 30))
-    monkeypatch.delenv("DP_CONV_ROWS_CHAIN", raising=False)
-    monkeypatch.delenv("DP_CONV_ROWS2_LOCKSTEP", raising=False)
-    if variant == "chain":
-        if Ci != 512:
-            pytest.skip("the chain form exists for 512 input channels")
-        monkeypatch.setenv("DP_CONV_ROWS_CHAIN", "1")
+    policy.default("conv_rows2_lockstep")
     if variant.startswith("rows2"):
         if not two_ok:
             pytest.skip("the 32-pixel form takes 512 input channels and widths with strip groups of at most 8 images")
-        monkeypatch.delenv("DP_CONV_ROWS2", raising=False)
-        monkeypatch.setenv("DP_CONV_ROWS2_256", "1")     # every 256-channel layer (default: only those the weight-stationary kernel does not take)
+        policy.default("conv_rows2")
+        policy.set("conv_rows2_256", "1")     # every 256-channel layer (default: only those the weight-stationary kernel does not take)
         if variant == "rows2_lockstep":
-            monkeypatch.setenv("DP_CONV_ROWS2_LOCKSTEP", "1")
+            policy.set("conv_rows2_lockstep", "1")
     else:
-        monkeypatch.setenv("DP_CONV_ROWS2", "0")
-    monkeypatch.setenv("DP_CONV_ROWS", "2")     # every shape the kernels take
+        policy.set("conv_rows2", "0")
+    policy.set("conv_rows", "2")     # every shape the kernels take
     g = torch.Generator().manual_seed(Ci + Co + N * 1000 + H * 10 + W)
     x = _round(torch.randn((N, Ci, H, W), generator=g), dt)
     w = _round(torch.randn((Co, Ci, 3, 3), generator=g) * (1.0 / (9 * Ci)) ** 0.5, dt)
@@ -585,18 +652,18 @@ def test_conv3x3_rows_kernel(eng, dt, case, variant, monkeypatch):
     # the default policy: a call site is on this kernel class for every batch or for none - 512-channel layers whose width suits the
     # 32-pixel form always (the DensePose head's ROI maps, sized on the device or not), other 512-channel layers on plain tensors
     # (res5's conv2) on the 16-pixel form; the 256 -> 512 layer and device-sized launches of other widths are not
-    monkeypatch.delenv("DP_CONV_ROWS")
+    policy.default("conv_rows")
     p.n_dev = None if n_dev is None else n_dev.data_ptr()
     if variant.startswith("rows2"):
         assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 8
         # 256 input channels: by default only the layers with another cout count (the head's 256 -> 512 first layer)
-        monkeypatch.delenv("DP_CONV_ROWS2_256")
+        policy.default("conv_rows2_256")
         assert (e.lib.dp_conv2d_kernel_class(C.byref(p)) == 8) == (Ci == 512 or Co != 256)
-        monkeypatch.setenv("DP_CONV_ROWS2_256", "1")
+        policy.set("conv_rows2_256", "1")
     else:
         assert (e.lib.dp_conv2d_kernel_class(C.byref(p)) == 7) == (Ci == 512 and live is None)     # (DP_CONV_ROWS2=0 in this variant)
     p.n_dev = None
-    monkeypatch.setenv("DP_CONV_ROWS", "2")
+    policy.set("conv_rows", "2")
     nl = N if live is None else live
     out = torch.full((N, H, W, Co), 7.0, dtype=e.tdt, device=e.device)      # slots behind the live count must stay untouched
     got = e.conv(layer, xa, relu=relu, out=out, n_dev=n_dev)
@@ -613,14 +680,14 @@ def test_conv3x3_rows_kernel(eng, dt, case, variant, monkeypatch):
         assert torch.equal(one.t[0], got.t[i]), i
     # a launch whose tensors exceed the 32-bit offset range goes as several launches over chunks of whole strip groups (never to
     # another kernel class): the limit lowered to a few images, same bits, same untouched slots, the live count cut across chunks
-    monkeypatch.setenv("DP_ROWS_CHUNK_BYTES", str(3 * H * W * max(Ci, Co) * 2))
+    policy.set("rows_chunk_bytes", str(3 * H * W * max(Ci, Co) * 2))
     out2 = torch.full((N, H, W, Co), 7.0, dtype=e.tdt, device=e.device)
     got2 = e.conv(layer, xa, relu=relu, out=out2, n_dev=n_dev)
     torch.cuda.synchronize()
     assert torch.equal(got2.t, got.t)
-    monkeypatch.delenv("DP_ROWS_CHUNK_BYTES")
+    policy.default("rows_chunk_bytes")
     # the ring kernels on the same operands: equal up to the summation order
-    monkeypatch.setenv("DP_CONV_ROWS", "0")
+    policy.set("conv_rows", "0")
     assert e.lib.dp_conv2d_kernel_class(C.byref(p)) not in (7, 8)
     want = e.conv(layer, xa, relu=relu)
     torch.cuda.synchronize()
@@ -672,7 +739,7 @@ def test_conv3x3_post_activation_sum(eng, dt, mode, shape):
 @pytest.mark.parametrize("dt", ["bf16", "fp16", "fp32"])
 @pytest.mark.parametrize("shape", [(2, 128, 256, 512, 25, 42, 2), (1, 256, 512, 1024, 13, 21, 2), (3, 64, 192, 256, 17, 9, 1),
                                    (8, 128, 256, 512, 50, 84, 2), (1, 512, 1024, 2048, 7, 11, 2)])
-def test_conv_pointwise_two_sources(eng, dt, shape, monkeypatch):
+def test_conv_pointwise_two_sources(eng, dt, shape, policy):
     """dp_conv_params.in2: out = relu(W1 x1 + W2 x2[::s, ::s] + b) as one pointwise layer whose K axis is x1's channels followed
     by x2's (conv3 of a stage's first bottleneck block + its projection shortcut, resnet.py:189-205), on both LDS-ring kernels,
     against torch in fp64."""
@@ -695,7 +762,7 @@ def test_conv_pointwise_two_sources(eng, dt, shape, monkeypatch):
     a2 = Act(_nhwc(x2, c2, e.tdt, e.device), N, H2, W2, c2)
     for force in (None, "2"):                  # the policy's choice and the 128x128 ring kernel
         if force:
-            monkeypatch.setenv("DP_CONV_BIG", force)
+            policy.set("conv_big", force)
         out = e.conv(layer, a1, relu=True, in2=a2, out_f32=True)
         torch.cuda.synchronize()
         got = out.t.cpu().permute(0, 3, 1, 2).double()
@@ -1255,7 +1322,7 @@ def test_preprocess_frames_equals_preprocess_of_the_stacked_batch(eng, dt, hwc):
     assert torch.equal(got, want.t)
 
 @pytest.mark.parametrize("geom", [(5, 56, 56, 80, 2, 25), (3, 28, 28, 96, 15, 25), (2, 9, 13, 80, 2, 25), (4, 7, 10, 80, 2, 25)])
-def test_iuv_upsample_split_forms_and_torch(eng, geom, monkeypatch):
+def test_iuv_upsample_split_forms_and_torch(eng, geom, policy):
     """dp_iuv_upsample_split (chart_predictor.py:45-70: bilinear x2 of the four predictor outputs, NHWC -> four NCHW tensors): the
     four-outputs-per-thread form with 16-byte stores (widths that are a multiple of 4) == the one-output form bit for bit, both ==
     F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) on the channel slices; a device-side live count leaves the
@@ -1269,7 +1336,7 @@ def test_iuv_upsample_split_forms_and_torch(eng, geom, monkeypatch):
     live = torch.tensor([R - 1], dtype=torch.int32, device=e.device)
     outs = {}
     for quad in ("1", "0"):
-        monkeypatch.setenv("DP_IUV_QUAD", quad)
+        policy.set("iuv_quad", quad)
         S0, S1 = 2 * Hs, 2 * Ws
         t = [torch.full((R, n, S0, S1), 7.0, device=e.device) for n in (nc, nf, nf, nf)]
         p = L.IuvParams()
@@ -1290,7 +1357,7 @@ def test_iuv_upsample_split_forms_and_torch(eng, geom, monkeypatch):
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("C_", [256, 128])
-def test_conv3x3_wsr_small_maps_equal_the_ring_kernel(eng, dt, C_, monkeypatch):
+def test_conv3x3_wsr_small_maps_equal_the_ring_kernel(eng, dt, C_, policy):
     """Round 4 lowered the weight-stationary 3x3 kernel's size line to 256 output pixels per launch (a single frame's p5 / p6 levels,
     fpn.py:134-135 / rpn.py:168 on 25 x 42 and 13 x 21 maps): on small, narrow and ragged maps it must equal the LDS-ring kernel bit for
     bit (the same K order) - which is why that line may depend on the batch."""
@@ -1309,12 +1376,12 @@ def test_conv3x3_wsr_small_maps_equal_the_ring_kernel(eng, dt, C_, monkeypatch):
         p.stride, p.ntaps, p.dtype, p.hi_off, p.wi_off, p.relu = 1, 9, e.dt, -1, -1, 1
         p.osN, p.osH, p.osW = H * W * C_, W * C_, C_
         p.out = 1
-        monkeypatch.delenv("DP_CONV_WS", raising=False)
+        policy.default("conv_ws")
         assert (e.lib.dp_conv2d_kernel_class(C.byref(p)) == 6) == (N * H * W >= 256 and H >= (6 if C_ == 256 else 8)), (N, H, W)
-        monkeypatch.setenv("DP_WS_MIN_M", "1")
+        policy.set("ws_min_m", "1")
         got = e.conv(layer, x, relu=True).t.clone()
-        monkeypatch.delenv("DP_WS_MIN_M")
-        monkeypatch.setenv("DP_CONV_WS", "0")
+        policy.default("ws_min_m")
+        policy.set("conv_ws", "0")
         assert e.lib.dp_conv2d_kernel_class(C.byref(p)) != 6
         want = e.conv(layer, x, relu=True).t
         torch.cuda.synchronize()
