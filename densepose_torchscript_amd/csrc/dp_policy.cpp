@@ -29,6 +29,7 @@ const Key kKeys[] = {
     {"conv_rows_chain", &DpPolicy::conv_rows_chain},
     {"rows_chunk_bytes", &DpPolicy::rows_chunk_bytes},
     {"conv_pws", &DpPolicy::conv_pws},
+    {"pws_skew", &DpPolicy::pws_skew},
     {"tail_kernel", &DpPolicy::tail_kernel},
     {"roi_tab", &DpPolicy::roi_tab},
     {"iuv_quad", &DpPolicy::iuv_quad},

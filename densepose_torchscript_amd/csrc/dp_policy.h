@@ -27,6 +27,7 @@ struct DpPolicy {
   int64_t rows_chunk_bytes = (1ll << 31) - 1;   // tensor bytes per launch of the row kernels (tests lower it)
   // weight-stationary pointwise (dp_conv_pw.hip)
   int64_t conv_pws = 1;             // 0 = never chosen
+  int64_t pws_skew = 0;             // (DP_EXPERIMENTS builds only) 1 = the halves of the workgroup half a step apart, two barriers per step
   // the rest
   int64_t tail_kernel = 0;          // dp_bottleneck_tail_nhwc: 1 = the tile kernel instead of the strip walker
   int64_t roi_tab = 1;              // dp_roi_align_nhwc: 0 = the per-sample kernel for every sampling ratio

@@ -178,7 +178,7 @@ PWS_CASES = [
     (1, 512, 37, 45, 256, False, "up"),      # fpn_lateral3 geometry class: one cout slice (odd sizes: "up" needs even ones -> below)
     (2, 2048, 25, 42, 512, True, None),      # res5 conv1: four K slices, 16-pixel steps
     (1, 2048, 26, 42, 256, False, None),     # fpn_lateral5
-    (3, 2048, 7, 9, 64, False, "lin"),       # one cout slice of 64, 189 pixels
+    (3, 2048, 7, 9, 128, False, "lin"),      # two cout slices of 64, 189 pixels
 ]
 
 

@@ -49,7 +49,9 @@ for name, N, H, W, Ci, Co, relu, rmode in LAYERS:
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
 
-    modes = {"pws": 1, "before": 0}
+    modes = {"pws": (1, 0), "before": (0, 0)}
+    if os.environ.get("SKEW"):       # `make exp` builds: the skewed schedule too
+        modes["pws-skew"] = (1, 1)
     L.set_policy("conv_pws", 1)
     t0 = time.time()
     while time.time() - t0 < 1.5:
@@ -57,10 +59,10 @@ for name, N, H, W, Ci, Co, relu, rmode in LAYERS:
     res = {m: [] for m in modes}
     for _ in range(3):
         for m, v in modes.items():
-            L.set_policy("conv_pws", v)
+            L.set_policy("conv_pws", v[0]); L.set_policy("pws_skew", v[1])
             res[m].append(run())
     for m in modes:
         ms = sorted(res[m])[1]
-        print("%-13s %dx%dx%d %4d->%-4d %s %-7s median %6.1f us (%s)  %5.0f TFLOP/s (%.3f)  %.2f TB/s algorithmic" % (
+        print("%-13s %dx%dx%d %4d->%-4d %s %-12s median %6.1f us (%s)  %5.0f TFLOP/s (%.3f)  %.2f TB/s algorithmic" % (
             name, N, H, W, Ci, Co, dt, m, ms * 1e3, " ".join("%.1f" % (v * 1e3) for v in res[m]), flops / ms / 1e9, flops / ms / 1e9 / 2500, nbytes / ms / 1e9), flush=True)
 L.reset_policy()
