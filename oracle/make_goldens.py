@@ -60,6 +60,11 @@ CASES = {
                         5, 31, (192, 300), ("dp_head_out/8",), 4),
     # BASELINE.json configs[4] combination: R101 + DeepLab head (pool 28) on a 1080x1920 video frame (-> 749x1333);
     # tiny channel widths keep the CPU replay short - the geometry (padding 768x1344, live dilated taps) is the real one
+    # BASELINE.json configs[4]'s combination at FULL channel width: R101 (res4 x 23) + DeepLab head at pool 28 (deeplab.py:64-144),
+    # reduced frame: the only full-width meeting of those kernels with the reference
+    "full_r101_dl_p28_small": ("densepose_rcnn_R_101_FPN_DL_s1x",
+                               ["INPUT.MIN_SIZE_TEST", 192, "INPUT.MAX_SIZE_TEST", 320, "TEST.DETECTIONS_PER_IMAGE", 2],
+                               9, 61, (192, 300), ("dp_head_out/8",), 4),
     "tiny_r101_dl_p28_video": ("densepose_rcnn_R_101_FPN_DL_s1x",
                                TINY_OPTS + ["INPUT.MIN_SIZE_TEST", 800, "INPUT.MAX_SIZE_TEST", 1333, "TEST.DETECTIONS_PER_IMAGE", 3],
                                6, 32, (1080, 1920), ("dp_head_out/1",), 4),
@@ -70,7 +75,12 @@ CASES = {
 # tensors (accumulating in float, rounding every layer's output to half). Recorded for cases that also have an fp32 golden, as
 # `<case>__half.npz` (outputs + visualiser labels only): the distance fp16-reference <-> fp32-reference is the yardstick the
 # engine's fp16 mode is held to (tests/test_gpu_e2e.py), and the engine must be about as close to this golden as to the fp32 one.
-HALF_CASES = ["tiny_r50_s1x_a", "full_r50_s1x_small", "tiny_r50_dl"]
+HALF_CASES = ["tiny_r50_s1x_a", "full_r50_s1x_small", "tiny_r50_dl", "full_r101_dl_p28_small"]
+# ... and the reference in bfloat16 (`predictor.bfloat16()`: the dtype every throughput configuration of BASELINE.json names; the
+# reference picks its dtype at run.py:20-29 / export.py:36-37 by calling .half() / .float() on the module - .bfloat16() is the same
+# nn.Module call). `<case>__bf16.npz`: the yardstick for the engine's bf16 mode - how far does the REFERENCE ITSELF move from its fp32
+# outputs when every weight and every layer output is rounded to bfloat16?
+BF16_CASES = ["tiny_r50_s1x_a", "full_r50_s1x_small", "tiny_r50_dl", "full_r50_dl_p28", "full_r101_dl_p28_small", "full_r50_s1x_800x1333"]
 
 
 def make_image(seed, hw):
@@ -87,11 +97,12 @@ def _import_visualizer():
     return visualizer
 
 
-def run_half_case(name):
+def run_half_case(name, mode="half"):
     cfg_name, opts, wseed, iseed, hw, stages, sub = CASES[name]
     cfg = get_config(cfg_name, opts)
     state = make_synthetic_state(cfg, wseed)
-    pred = build_reference_predictor(cfg, state).half()
+    pred = build_reference_predictor(cfg, state)
+    pred = pred.half() if mode == "half" else pred.bfloat16()
     out = pred(torch.from_numpy(make_image(iseed, hw)))
     arrays = {}
     for k, v in out.items():
@@ -104,13 +115,35 @@ def run_half_case(name):
     results, _ = vis.DensePoseResultExtractor()({k: (v.float() if v.is_floating_point() else v) for k, v in out.items()})
     for i, r in enumerate(results):
         arrays["vis/labels_%d" % i] = r["labels"].numpy().astype(np.uint8)
-    meta = dict(case=name + "__half", config=cfg_name, opts=list(opts), weight_seed=wseed, image_seed=iseed, image_hw=list(hw),
-                iuv_stride=sub, weights_sha256=state_checksum(state), torch=torch.__version__, mode="reference .half() on CPU",
-                generator="oracle/make_goldens.py --half (reference imported from /root/reference)")
+    # ... and the same labels computed on the boxes of the FP32 golden's detections (nearest box within 1.5 px): the part-label agreement
+    # of the reference's own low-precision run with its fp32 run - on identical pixel grids - is then a plain comparison with the fp32
+    # golden's vis/labels_<i> (tests/test_oracle_golden.py, and the yardstick of the GPU tests)
+    fp32_path = os.path.join(GOLDEN_DIR, name + ".npz")
+    if os.path.exists(fp32_path):
+        z32 = np.load(fp32_path)
+        rb = z32["out/pred_boxes"]
+        gb = out["pred_boxes"].float().numpy()
+        match = np.full((len(rb),), -1, dtype=np.int32)
+        for i in range(len(rb)):
+            if len(gb) == 0:
+                break
+            d = np.abs(gb - rb[i]).max(axis=1)
+            j = int(d.argmin())
+            if d[j] < 1.5:
+                match[i] = j
+                inst = {k: out[k][j:j + 1].float() for k in out if k.startswith("pred_densepose")}
+                inst["pred_boxes"] = torch.from_numpy(rb[i:i + 1].copy())
+                (r,), _ = vis.DensePoseResultExtractor()(inst)
+                arrays["vis/labels_on_fp32_box_%d" % i] = r["labels"].numpy().astype(np.uint8)
+        arrays["match/fp32_to_this"] = match
+    call = ".half()" if mode == "half" else ".bfloat16()"
+    meta = dict(case=name + "__" + mode, config=cfg_name, opts=list(opts), weight_seed=wseed, image_seed=iseed, image_hw=list(hw),
+                iuv_stride=sub, weights_sha256=state_checksum(state), torch=torch.__version__, mode="reference %s on CPU" % call,
+                generator="oracle/make_goldens.py --%s (reference imported from /root/reference)" % mode)
     arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
-    path = os.path.join(GOLDEN_DIR, name + "__half.npz")
+    path = os.path.join(GOLDEN_DIR, name + "__%s.npz" % mode)
     np.savez_compressed(path, **arrays)
-    print("%-26s R=%d  %.2f MB (half)" % (name, len(out["scores"]), os.path.getsize(path) / 1e6), flush=True)
+    print("%-26s R=%d  %.2f MB (%s)" % (name, len(out["scores"]), os.path.getsize(path) / 1e6, mode), flush=True)
 
 
 def run_case(name):
@@ -191,13 +224,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--half", action="store_true", help="record the <case>__half.npz fixtures (reference .half() on CPU) instead")
+    ap.add_argument("--bf16", action="store_true", help="record the <case>__bf16.npz fixtures (reference .bfloat16() on CPU) instead")
     args = ap.parse_args()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
-    if args.half:
-        for name in HALF_CASES:
+    if args.half or args.bf16:
+        for name in (HALF_CASES if args.half else BF16_CASES):
             if not args.only or args.only == name:
-                run_half_case(name)
+                run_half_case(name, "half" if args.half else "bf16")
         return
     for name in CASES:
         if args.only and args.only != name:
