@@ -117,8 +117,31 @@ def accuracy_vs_golden(pred, dtype):
         if tot:
             labels = {"label_agreement": round(eq / tot, 5), "label_agreement_foreground": round(eq_fg / max(tot_fg, 1), 5),
                       "label_pixels": tot, "label_note": "vis/labels_* of the golden vs dp_iuv_extract on this run's maps, matched detections, full resolution"}
+    # the reference's OWN run in this dtype on the same frame (tests/golden/..__bf16.npz: predictor.bfloat16() on the CPU, run.py:20-29 /
+    # export.py:36-37) and this run, both against the fp32 golden under ONE definition (tests/yardstick.py: a detection counts as found
+    # when the nearest box is within 1.5 px; IUV deviation relative to the map's largest fp32 value; labels on the fp32 run's boxes)
+    yard = None
+    lp = os.path.join(ROOT, "tests", "golden", "full_r50_s1x_800x1333__%s.npz" % {"bf16": "bf16", "fp16": "half"}.get(dtype, "none"))
+    if os.path.exists(lp):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        try:
+            from yardstick import engine_distance, lowp_distance_from_fixtures
+            from densepose_torchscript_amd.visualizer import extract_iuv as _gpu_extract
+
+            def _extract(sub):      # the GPU visualiser extract (dp_iuv_extract) in the CPU oracle's calling convention
+                res, _ = _gpu_extract({k: v.to(pred.device) for k, v in sub.items()})
+                return [(r["labels"].cpu(), None) for r in res]
+            cpu_out = {k: v.float().cpu() if v.is_floating_point() else v.cpu() for k, v in out.items()}
+            rnd = lambda d: {k: (round(v, 5) if isinstance(v, float) else v) for k, v in d.items()}   # noqa: E731
+            yard = {"definition": "tests/yardstick.py", "this_run": rnd(engine_distance(cpu_out, z, s, _extract)),
+                    "reference_in_this_dtype": rnd(lowp_distance_from_fixtures(z, np.load(lp))),
+                    "reference_fixture": os.path.relpath(lp, ROOT),
+                    "note": "seeded random weights: detections sit next to the score threshold, so both runs lose some of the fp32 run's "
+                            "detections; a real checkpoint cannot be evaluated here (no .pkl on either box)"}
+        finally:
+            sys.path.pop(0)
     return {"reference": "tests/golden/full_r50_s1x_800x1333.npz (fp32, recorded from the imported reference)", "dtype": dtype,
-            **(labels or {}),
+            **(labels or {}), **({"yardstick": yard} if yard else {}),
             "ref_detections": int(len(rb)), "detections": int(len(boxes)), "box_match_rate": round(matched / max(len(rb), 1), 3),
             "max_abs_box_err_px": round(box_err, 4), "max_abs_score_err": round(score_err, 5),
             "max_abs_iuv_err_on_matched": round(iuv_err, 4), "iuv_samples": "every %dth pixel of the 112x112 maps" % s}

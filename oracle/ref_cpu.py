@@ -85,7 +85,7 @@ class OracleModel:
 
     # ---------------------------------------------------------------- resnet.py:350-354,189-205,430-453
     def resnet(self, x):
-        from densepose_torchscript_amd.weights import resnet_blocks
+        from oracle.structure import resnet_blocks
         bu = "backbone.bottom_up."
         x = self.conv(x, bu + "stem.conv1", stride=2, padding=3)
         x = F.relu_(self.frozen_bn(x, bu + "stem.conv1.norm"))
@@ -288,7 +288,7 @@ class OracleModel:
 
     # ---------------------------------------------------------------- roi_head.py:71-79 (Decoder)
     def decoder(self, features):
-        from densepose_torchscript_amd.weights import decoder_layout
+        from oracle.structure import decoder_layout
         x = None
         for lvl, n in decoder_layout(self.cfg):
             t = features[lvl]

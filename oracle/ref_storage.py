@@ -99,7 +99,7 @@ class StorageOracle(OracleModel):
 
     # ---------------------------------------------------------------- resnet.py
     def resnet(self, x):
-        from densepose_torchscript_amd.weights import resnet_blocks
+        from oracle.structure import resnet_blocks
         bu = "backbone.bottom_up."
         x = self.bnconv(x, bu + "stem.conv1", stride=2, padding=3)           # the conv rows are rounded before the pool reads them
         x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
@@ -184,7 +184,7 @@ class StorageOracle(OracleModel):
 
     # ---------------------------------------------------------------- roi_head.py:71-79
     def decoder(self, features):
-        from densepose_torchscript_amd.weights import decoder_layout
+        from oracle.structure import decoder_layout
         up = lambda t: F.interpolate(t, scale_factor=2.0, mode="bilinear", align_corners=False)   # noqa: E731
         name = lambda lvl, k: "roi_heads.decoder.%s.%d" % (lvl, 2 * k)                               # noqa: E731
         layout = decoder_layout(self.cfg)

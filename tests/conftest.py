@@ -36,7 +36,7 @@ def golden_case_inputs(meta):
 
 
 ALL_GOLDENS = ["tiny_r50_s1x_a", "tiny_r50_s1x_b", "tiny_r50_legacy", "tiny_r101_s1x", "tiny_r50_dl", "tiny_r101_dl",
-               "full_r50_s1x_small", "full_r101_s1x_small", "full_r50_legacy_small", "full_r50_s1x_800x1333", "full_r50_dl_p28", "tiny_r101_dl_p28_video"]
+               "full_r50_s1x_small", "full_r101_s1x_small", "full_r50_legacy_small", "full_r50_s1x_800x1333", "full_r50_dl_p28", "full_r101_dl_p28_small", "tiny_r101_dl_p28_video"]
 
 
 @pytest.fixture(scope="session")

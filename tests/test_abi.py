@@ -91,6 +91,26 @@ def test_product_never_imports_oracle():
                 assert "/root/reference" not in re.sub(r'""".*?"""', "", s, flags=re.S).replace("# ", ""), f
 
 
+def test_oracle_restates_the_network_structure_itself():
+    """The converse for the two structure helpers: the checker (oracle/ref_cpu.py, oracle/ref_storage.py) walks the block table and the
+    decoder layout of oracle/structure.py (restated from resnet.py:641-688 / roi_head.py:42-68), never the product's
+    densepose_torchscript_amd.weights.resnet_blocks / decoder_layout - and the two restatements agree on every BASELINE configuration."""
+    from densepose_torchscript_amd import get_config
+    from densepose_torchscript_amd import weights as W
+    from oracle import structure as S
+    for f in ("ref_cpu.py", "ref_storage.py", "ops_ref.py", "structure.py"):
+        src = open(os.path.join(ROOT, "oracle", f)).read()
+        assert not re.search(r"densepose_torchscript_amd\.weights\s+import\s+[^\n]*(resnet_blocks|decoder_layout)", src), f
+    for name in ("densepose_rcnn_R_50_FPN_s1x_legacy", "densepose_rcnn_R_50_FPN_s1x", "densepose_rcnn_R_101_FPN_s1x",
+                 "densepose_rcnn_R_50_FPN_DL_s1x", "densepose_rcnn_R_101_FPN_DL_s1x"):
+        cfg = get_config(name, [])
+        assert list(S.resnet_blocks(cfg)) == list(W.resnet_blocks(cfg)), name
+        assert list(S.decoder_layout(cfg)) == list(W.decoder_layout(cfg)), name
+    r101 = S.resnet_blocks(get_config("densepose_rcnn_R_101_FPN_s1x", []))
+    assert [sum(1 for b in r101 if b[0] == "res%d" % k) for k in (2, 3, 4, 5)] == [3, 4, 23, 3]       # resnet.py:641-647
+    assert [(b[0], b[5], b[6]) for b in r101 if b[1] == 0] == [("res2", 1, True), ("res3", 2, True), ("res4", 2, True), ("res5", 2, True)]
+
+
 def test_no_kernel_uses_scratch(built, tmp_path):
     """No gfx950 kernel of the library spills or keeps a private array: zero scratch_ instructions in the disassembly and a
     zero .private_segment_fixed_size in every kernel descriptor (round 3 shipped the two-source LDS-ring instances with 20 bytes

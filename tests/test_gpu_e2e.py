@@ -44,7 +44,7 @@ def _assert_rows_match(boxes, scores, ref_boxes, ref_scores, score_tol=1e-4, box
 TINY = ["tiny_r50_s1x_a", "tiny_r50_s1x_b", "tiny_r50_legacy", "tiny_r101_s1x", "tiny_r50_dl", "tiny_r101_dl"]
 
 
-@pytest.mark.parametrize("name", TINY + ["full_r50_s1x_small", "full_r101_s1x_small", "full_r50_legacy_small", "full_r50_s1x_800x1333", "full_r50_dl_p28", "tiny_r101_dl_p28_video"])
+@pytest.mark.parametrize("name", TINY + ["full_r50_s1x_small", "full_r101_s1x_small", "full_r50_legacy_small", "full_r50_s1x_800x1333", "full_r50_dl_p28", "full_r101_dl_p28_small", "tiny_r101_dl_p28_video"])
 def test_fp32_matches_reference_golden(name):
     from oracle.ref_cpu import extract_iuv
     meta, z, cfg, pred, out = _run(name, "fp32", keep=True)
@@ -245,7 +245,7 @@ def _label_agreement(out, z, box_tol):
 # the storage type where the engine stores it. tools/emul_layers.py / tools/emul_stats.py print what the bounds below were read from.
 TOP_ULP = {"bf16": 2.0 ** -7, "fp16": 2.0 ** -10}     # one unit in the last place of a tensor's largest value, relative to it
 FORCED_CASES = [("full_r50_s1x_small", "bf16"), ("full_r50_s1x_small", "fp16"), ("full_r50_s1x_800x1333", "bf16"), ("full_r101_s1x_small", "bf16"),
-                ("full_r50_dl_p28", "bf16"), ("tiny_r101_dl_p28_video", "fp16"), ("tiny_r101_dl_p28_video", "bf16"), ("tiny_r50_legacy", "bf16"),
+                ("full_r50_dl_p28", "bf16"), ("full_r101_dl_p28_small", "fp16"), ("tiny_r101_dl_p28_video", "fp16"), ("tiny_r101_dl_p28_video", "bf16"), ("tiny_r50_legacy", "bf16"),
                 ("full_r50_legacy_small", "bf16")]
 
 
@@ -397,7 +397,7 @@ def test_fp16_mode_matches_reference_half_semantics(name):
     assert npx > 0 and agree >= FP16_LABEL_FLOOR, (name, agree)
 
 
-@pytest.mark.parametrize("name", ["tiny_r50_s1x_a", "full_r50_s1x_small", "tiny_r50_dl"])
+@pytest.mark.parametrize("name", ["tiny_r50_s1x_a", "full_r50_s1x_small", "tiny_r50_dl", "full_r101_dl_p28_small"])
 def test_fp16_mode_against_the_reference_run_in_half(name):
     """The reference's OWN fp16 mode (`predictor.half()`, run.py:26) recorded on the CPU (tests/golden/<case>__half.npz,
     oracle/make_goldens.py --half): ATen's CPU half kernels round every layer's output to half like this engine does, but keep
@@ -419,6 +419,33 @@ def test_fp16_mode_against_the_reference_run_in_half(name):
     hits_h, iuv_h = _match_to_reference(out, zh, s, 0.5, 0.02)
     assert hits_h >= zh["out/scores"].shape[0] - 1, hits_h
     assert iuv_h <= max(3.0 * ref_iuv, 0.03), (iuv_h, ref_iuv)
+
+
+BF16_REF_CASES = ["tiny_r50_s1x_a", "full_r50_s1x_small", "tiny_r50_dl", "full_r50_dl_p28", "full_r101_dl_p28_small", "full_r50_s1x_800x1333"]
+
+
+@pytest.mark.parametrize("name", BF16_REF_CASES)
+def test_bf16_mode_against_the_reference_run_in_bfloat16(name):
+    """The dtype every throughput configuration of BASELINE.json names, held to the reference's OWN run in that dtype
+    (`predictor.bfloat16()` recorded on the CPU: tests/golden/<case>__bf16.npz, oracle/make_goldens.py --bf16; the reference picks its
+    dtype by such a module call, run.py:20-29 / export.py:36-37). ATen's CPU bf16 kernels round every layer's output - and FrozenBN's
+    intermediate results, and the box arithmetic - to 8 significant bits; the engine folds FrozenBN into the weights, accumulates in fp32
+    and keeps boxes / scores / NMS in fp32. So: the engine's bf16 outputs must be NO FURTHER from the reference's fp32 outputs than the
+    reference's own bf16 outputs are - detections found, IUV deviation on the matched ones, part-label agreement (tests/yardstick.py:
+    one definition for both sides)."""
+    from oracle.ref_cpu import extract_iuv
+    from yardstick import engine_distance, reference_lowp_distance
+    meta, z, cfg, pred, out = _run(name, "bf16")
+    ref = reference_lowp_distance(name, "bf16")
+    eng = engine_distance(out, z, meta["iuv_stride"], extract_iuv)
+    print("\n%s: engine bf16 %s\n%s  reference bf16 %s" % (name, eng, " " * len(name), ref))
+    R = eng["ref_detections"]
+    assert abs(eng["detections"] - R) <= 1
+    assert eng["box_match_rate"] >= ref["box_match_rate"] - 1e-9, (eng, ref)              # finds at least as many of the fp32 detections
+    if ref["label_pixels"] > 0 and eng["label_pixels"] > 0:
+        assert eng["label_agreement"] >= ref["label_agreement"] - 0.02, (eng, ref)        # part labels at least as close (2 % slack: other matched set)
+    if ref["box_match_rate"] > 0:
+        assert eng["iuv"] <= max(1.5 * ref["iuv"], 0.08), (eng, ref)                      # IUV maps of the matched detections
 
 
 def test_missing_gpu_or_library_fails_loudly(monkeypatch):
