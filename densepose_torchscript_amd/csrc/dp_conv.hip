@@ -61,6 +61,10 @@ struct ConvArgs {
   float* head_out;        // [M][16] fp32
   int split_k;            // > 1: the K planes are cut into split_k segments, workgroup (tile, blockIdx.y) accumulates segment blockIdx.y
   float* split_ws;        //      and writes its raw fp32 sums to split_ws[segment][M][Cout] (dp_conv_params.split_k)
+  int n_groups;           // > 1: grouped launch (dp_conv_params.n_groups): tile = (pixel tile, group, cout tile); group g runs on
+  const void* weight_g[4];   //  weight_g[g] / ktab_g[g] and stores at out_g[g]; tiles_n counts the cout tiles of ONE group
+  const i32x4* ktab_g[4];
+  void* out_g[4];
 };
 
 // 16 zero bytes in global memory: out-of-image / K-padding chunks are loaded from here, so every staging load is
@@ -76,7 +80,7 @@ __device__ u32x4 g_zero16 = {0u, 0u, 0u, 0u};
 // four lanes of a pixel covering 64 contiguous bytes of the NHWC row per instruction: no LDS staging tile, no barrier,
 // and the operand ring stays free for the next tile.
 template <typename T, int TP>
-__device__ __forceinline__ void store_tile(const ConvArgs& p, const f32x4 (&acc)[4][TP], int m_wave, int n_wave, int fr, int fq) {
+__device__ __forceinline__ void store_tile(const ConvArgs& p, void* out, const f32x4 (&acc)[4][TP], int m_wave, int n_wave, int fr, int fq) {
   const T* __restrict__ res = reinterpret_cast<const T*>(p.residual);
   const bool f32_out = p.out_f32 || sizeof(T) == 4;
   const bool linear = p.out_linear && (!res || p.res_linear);
@@ -129,8 +133,8 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, const f32x4 (&acc)
         for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
       }
       if (row_ok) {
-        if (f32_out) store8(reinterpret_cast<float*>(p.out) + ob + c, v);
-        else store8(reinterpret_cast<T*>(p.out) + ob + c, v);
+        if (f32_out) store8(reinterpret_cast<float*>(out) + ob + c, v);
+        else store8(reinterpret_cast<T*>(out) + ob + c, v);
       }
     }
   }
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_kernel(const ConvArgs 
   }
 
   // ---- epilogue straight from the accumulators ----
-  store_tile<T, TP>(p, acc, m0 + wp * TP * 16, n0 + wc * 64, fr, fq);
+  store_tile<T, TP>(p, p.out, acc, m0 + wp * TP * 16, n0 + wc * 64, fr, fq);
 }
 
 #undef DP_STAGE_TILE
@@ -393,11 +397,18 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
     const int q = nwg >> 3, r = nwg & 7, x = b & 7;
     tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
   }
-  const int mt = tile / p.tiles_n;
-  const int nt = tile - mt * p.tiles_n;
+  // grouped launch (the chart predictor's four sub-pixel convolutions, chart.py:45-60): tile = (pixel tile, group, cout tile) - the
+  // groups of a pixel tile are neighbours in the numbering, i.e. on one XCD, and read the same input rows
+  const int tpg = p.tiles_n * (p.n_groups > 1 ? p.n_groups : 1);
+  const int mt = tile / tpg;
+  const int grp = (tile - mt * tpg) / p.tiles_n;
+  const int nt = tile - mt * tpg - grp * p.tiles_n;
   const int m0 = mt * BM;
   const int n0 = nt * BN;
   if (p.n_dev != nullptr && m0 >= *p.n_dev * p.HoWo) return;   // (uniform: a scalar load) nothing live in this tile
+  const void* const g_weight = p.n_groups > 1 ? p.weight_g[grp] : p.weight;
+  const i32x4* const g_ktab = p.n_groups > 1 ? p.ktab_g[grp] : p.ktab;
+  void* const g_out = p.n_groups > 1 ? p.out_g[grp] : p.out;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -409,7 +420,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
   const int scc = (lane & 3) ^ swz(srow);
 
   // constant address space: the only way to get s_load (a vector load here would sit in vmcnt and drain the ring)
-  const __attribute__((address_space(4))) i32x4* ktab_c = (const __attribute__((address_space(4))) i32x4*)p.ktab;
+  const __attribute__((address_space(4))) i32x4* ktab_c = (const __attribute__((address_space(4))) i32x4*)g_ktab;
 
   // per-lane descriptors of the two pixel rows this lane stages (rows 32*wave + 16*i + srow of the tile):
   // byte offset of (row, tap (0,0), this lane's chunk) - possibly "virtual" at the border - and a bit mask of the taps
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
   const int w_planes = p.Kpad * ES / 64;
   const int w_boff = (int)dp_wtile_off(n0 + wave * 32 + srow, 0, scc, w_planes) + s_base * 1024;
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_weight), 0, p.w_bytes, 0x00020000);
   // Second source of a pointwise layer (the projection shortcut of a bottleneck's first block as extra K planes of its conv3,
   // resnet.py:189-205: out = relu(W3 t2 + Ws x[::s, ::s] + b)): K channels >= Cin are read from in2 at pixel (ho * stride2,
   // wo * stride2). The plane's source is wave-uniform (its channel offset comes from the scalar tap table).
@@ -681,7 +692,7 @@ __global__ __launch_bounds__(WC * 2 * 64, 2) void conv_ring_kernel(const ConvArg
 
   // ---- epilogue straight from the accumulators ----
   if constexpr (SPLIT) store_tile_partial<TP>(p.split_ws + (long long)blockIdx.y * p.M * p.Cout, p.M, p.Cout, acc, m0 + wp * TP * 16, n0 + wc * 64, fr, fq);
-  else store_tile<T, TP>(p, acc, m0 + wp * TP * 16, n0 + wc * 64, fr, fq);
+  else store_tile<T, TP>(p, g_out, acc, m0 + wp * TP * 16, n0 + wc * 64, fr, fq);
 }
 #undef DP_RING_STAGE
 #undef DP_RING_READ
@@ -772,11 +783,18 @@ __global__ __launch_bounds__(512, 4) void conv_ring2_kernel(const ConvArgs p) {
     const int q = nwg >> 3, r = nwg & 7, x = b & 7;
     tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
   }
-  const int mt = tile / p.tiles_n;
-  const int nt = tile - mt * p.tiles_n;
+  // grouped launch (the chart predictor's four sub-pixel convolutions, chart.py:45-60): tile = (pixel tile, group, cout tile) - the
+  // groups of a pixel tile are neighbours in the numbering, i.e. on one XCD, and read the same input rows
+  const int tpg = p.tiles_n * (p.n_groups > 1 ? p.n_groups : 1);
+  const int mt = tile / tpg;
+  const int grp = (tile - mt * tpg) / p.tiles_n;
+  const int nt = tile - mt * tpg - grp * p.tiles_n;
   const int m0 = mt * BM;
   const int n0 = nt * BN;
   if (p.n_dev != nullptr && m0 >= *p.n_dev * p.HoWo) return;   // (uniform: a scalar load) nothing live in this tile
+  const void* const g_weight = p.n_groups > 1 ? p.weight_g[grp] : p.weight;
+  const i32x4* const g_ktab = p.n_groups > 1 ? p.ktab_g[grp] : p.ktab;
+  void* const g_out = p.n_groups > 1 ? p.out_g[grp] : p.out;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -786,7 +804,7 @@ __global__ __launch_bounds__(512, 4) void conv_ring2_kernel(const ConvArgs p) {
 
   const int srow = lane >> 2;
   const int scc = (lane & 3) ^ swz(srow);
-  const __attribute__((address_space(4))) i32x4* ktab_c = (const __attribute__((address_space(4))) i32x4*)p.ktab;
+  const __attribute__((address_space(4))) i32x4* ktab_c = (const __attribute__((address_space(4))) i32x4*)g_ktab;
 
   // staging: A plane = 16 pieces of 16 rows (2 per wave: rows 32*wave + 16*i + srow), B plane = 8 pieces (1 per wave)
   int a_boff[2];
@@ -812,7 +830,7 @@ __global__ __launch_bounds__(512, 4) void conv_ring2_kernel(const ConvArgs p) {
   const int w_planes = p.Kpad * ES / 64;
   const int w_boff = (int)dp_wtile_off(n0 + wave * 16 + srow, 0, scc, w_planes);   // tile (n0 / 16 + wave, plane 0) of the tiled weight matrix
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.weight), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g_weight), 0, p.w_bytes, 0x00020000);
   unsigned char* const lds_sa = smem + wave * 2048;             // this wave's 2 KiB of an A plane
   unsigned char* const lds_sb = smem + A_PLANE + wave * 1024;   // this wave's 1 KiB of a B plane
 
@@ -871,7 +889,7 @@ __global__ __launch_bounds__(512, 4) void conv_ring2_kernel(const ConvArgs p) {
   }
 
   // ---- epilogue straight from the accumulators ----
-  store_tile<T, TP>(p, acc, m0 + wp * TP * 16, n0 + wc * 64, fr, fq);
+  store_tile<T, TP>(p, g_out, acc, m0 + wp * TP * 16, n0 + wc * 64, fr, fq);
 }
 
 template <typename T>
@@ -1266,7 +1284,7 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   DP_REQUIRE(p->N >= 0 && p->H > 0 && p->W > 0 && p->Ho > 0 && p->Wo > 0, "dp_conv2d_nhwc: bad spatial shape");
   const long long M = (long long)p->N * p->Ho * p->Wo;
   if (M == 0) return DP_OK;  // R = 0 detections is legal
-  DP_REQUIRE(p->in && p->weight && p->ktab && p->bias && (p->out || p->head_out), "dp_conv2d_nhwc: null pointer");
+  DP_REQUIRE(p->in && p->bias && ((p->weight && p->ktab && (p->out || p->head_out)) || p->n_groups > 1), "dp_conv2d_nhwc: null pointer");
   DP_REQUIRE(p->Cin > 0 && p->Cin % 8 == 0, "dp_conv2d_nhwc: Cin=%d must be a positive multiple of 8", p->Cin);
   DP_REQUIRE(p->Cout > 0 && p->Cout % 8 == 0 && p->Cout <= p->Cout_w, "dp_conv2d_nhwc: Cout=%d Cout_w=%d", p->Cout, p->Cout_w);
   DP_REQUIRE(p->Cout_w % 128 == 0, "dp_conv2d_nhwc: Cout_w=%d must be a multiple of 128", p->Cout_w);
@@ -1289,6 +1307,15 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   a.in2 = p->in2; a.H2 = p->H2; a.W2 = p->W2; a.Cin2 = p->Cin2; a.stride2 = p->stride2;
   a.in2_bytes = p->in2 ? (unsigned)((long long)p->N * p->H2 * p->W2 * p->Cin2 * es) : 0u;
   a.split_k = 0; a.split_ws = nullptr;
+  a.n_groups = 0;
+  for (int g = 0; g < 4; ++g) { a.weight_g[g] = nullptr; a.ktab_g[g] = nullptr; a.out_g[g] = nullptr; }
+  if (p->n_groups > 1) {
+    DP_REQUIRE(p->n_groups <= 4, "dp_conv2d_nhwc: n_groups=%d (at most 4)", p->n_groups);
+    for (int g = 0; g < p->n_groups; ++g)
+      DP_REQUIRE(p->weight_g[g] && p->ktab_g[g] && p->out_g[g], "dp_conv2d_nhwc: group %d of %d: null weight / ktab / out", g, p->n_groups);
+    DP_REQUIRE(!p->in2 && !p->head_out && !p->post_res && p->post_mode == 0 && p->split_k <= 1 && !p->residual,
+               "dp_conv2d_nhwc: a grouped launch takes no second source / fused head / post_res / split_k / residual");
+  }
   if (p->in2) {
     DP_REQUIRE(p->ntaps == 1 && p->stride == 1 && p->hi_off == 0 && p->wi_off == 0 && p->H == p->Ho && p->W == p->Wo,
                "dp_conv2d_nhwc: a second source needs a pointwise stride-1 layer");
@@ -1324,6 +1351,12 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   }
   const int kc = choose_conv_kernel(p, M);
   if (kc < 0) return dp_fail(DP_ERR_UNSUPPORTED, "dp_conv2d_nhwc: a second source needs a shape the LDS-ring kernels take");
+  if (p->n_groups > 1) {
+    if (kc != DP_CONV_RING128 && kc != DP_CONV_RING256x128)
+      return dp_fail(DP_ERR_UNSUPPORTED, "dp_conv2d_nhwc: a grouped launch runs on the 128-cout LDS-ring kernels (kernel classes 3 / 4) only; this layer is class %d", kc);
+    a.n_groups = p->n_groups;
+    for (int g = 0; g < p->n_groups; ++g) { a.weight_g[g] = p->weight_g[g]; a.ktab_g[g] = reinterpret_cast<const i32x4*>(p->ktab_g[g]); a.out_g[g] = p->out_g[g]; }
+  }
   if (p->head_out) {
     // fused 1x1 head: the 256-cout ring kernel only (all channels of a pixel in one workgroup), 16-bit storage, ReLU hidden layer
     DP_REQUIRE(p->head_w && p->head_b, "dp_conv2d_nhwc: head_out given without head_w / head_b");
@@ -1358,14 +1391,15 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
       default: { DP_BY_DTYPE((launch_conv_ring<T, 4, 8>(a, s))); }
     }
   }
+  const int n_grp = p->n_groups > 1 ? p->n_groups : 1;
   if (kc == DP_CONV_RING256x128) {
     a.tiles_n = (p->Cout + 127) / 128;
-    a.n_tiles = (int)((M + 255) / 256) * a.tiles_n;
+    a.n_tiles = (int)((M + 255) / 256) * a.tiles_n * n_grp;
     DP_BY_DTYPE((launch_conv_ring2<T>(a, s)));
   }
   if (kc == DP_CONV_RING128) {
     a.tiles_n = (p->Cout + 127) / 128;
-    a.n_tiles = (int)((M + 127) / 128) * a.tiles_n;
+    a.n_tiles = (int)((M + 127) / 128) * a.tiles_n * n_grp;
     DP_BY_DTYPE((launch_conv_ring<T, 2, 4>(a, s)));
   }
   const int tiles_m = (int)((M + kBM - 1) / kBM);

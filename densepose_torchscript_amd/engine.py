@@ -92,6 +92,7 @@ class Engine:
         self.fuse_bottleneck = True   # res2 blocks: conv2 -> conv3 -> next conv1 in one launch (bottleneck_tail)
         self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
         self.fuse_shortcut = _os.environ.get("DP_FUSE_SHORTCUT", "1") != "0"   # block-0 projection shortcut as K planes of conv3 (16-bit modes)
+        self.group_deconv = _os.environ.get("DP_GROUP_DECONV", "1") != "0"   # A/B knob: 0 = the predictor's four sub-pixel convolutions as four launches
         self.split_k_on = _os.environ.get("DP_SPLIT_K", "1") != "0"   # A/B knob: layers with PackedConv.split_k run unsplit
         self.decoder_fold = True      # 16-bit modes: the decoder's level sum in the conv epilogues (post_res) instead of a merge pass
         self._shared_chip = 0         # dp_conv_params.shared_chip of the launches being issued: 1 beside other large launches, 2 beside the top-k / NMS chain
@@ -164,14 +165,16 @@ class Engine:
         return torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
 
     def conv(self, layer, x, relu=False, residual=None, rshift=0, out_f32=False, out=None, out_c_stride=None, out_c_off=0,
-             out_geom=None, out_hw=None, head=None, post=None, post_mode=0, n_dev=None, in2=None):
+             out_geom=None, out_hw=None, head=None, post=None, post_mode=0, n_dev=None, in2=None, groups=None):
         """x: Act. Returns Act. out_geom: (osN, osH, osW, base_elems) override for the sub-pixel deconv; out_hw: (Ho, Wo)
         override (the paired-pixel stem, whose input is narrower than its output is wide). head: (weight [16, Cout], bias [16],
         macs per pixel) of a fused 1x1 head on this layer's ReLU output - the call then returns the HEAD's fp32 output
         [N, Ho, Wo, 16] and the hidden tensor is never written (caller checks head_fusable first). post / post_mode: an Act added
         AFTER the activation (dp_conv_params.post_res: 1 = same geometry, 2 = half-size map through a bilinear x2; caller checks
         post_fusable first). n_dev: int32 device tensor [1] = how many of the x.N images hold data (dp_conv_params.n_dev).
-        in2: second source Act of a pack.dual_source_pointwise layer (dp_conv_params.in2), read at stride layer.stride2."""
+        in2: second source Act of a pack.dual_source_pointwise layer (dp_conv_params.in2), read at stride layer.stride2.
+        groups: [(layer_g, base element of its output inside `out`)] - 2 .. 4 layers of `layer`'s geometry in ONE launch
+        (dp_conv_params.n_groups; out_geom gives the shared strides, its base is ignored; caller checks groups_fusable first)."""
         if (in2 is not None or post is not None) and head is None and out_geom is None and out_c_stride is None and not out_f32:
             # The kernels behind in2 / post address their tensors with 32-bit byte offsets: a batch whose largest tensor exceeds
             # 2 GiB (64 frames of 800x1344 at the res3 / p2 levels) goes image chunk by image chunk. Per-pixel arithmetic does not
@@ -246,6 +249,13 @@ class Engine:
         if post is not None:
             assert post.C == layer.cout and post.N == N and (post.H, post.W) == ((Ho, Wo) if post_mode == 1 else (Ho // 2, Wo // 2))
             p.post_res, p.post_mode = post.t.data_ptr(), post_mode
+        if groups is not None:
+            assert out_geom is not None and 2 <= len(groups) <= 4 and residual is None and head is None and in2 is None and post is None
+            p.n_groups = len(groups)
+            for g, (lg, base) in enumerate(groups):
+                assert (lg.cout, lg.cout_w, lg.kpad, lg.ntaps, lg.stride, lg.hi_off, lg.wi_off) == (
+                    layer.cout, layer.cout_w, layer.kpad, layer.ntaps, layer.stride, layer.hi_off, layer.wi_off), lg.name
+                p.weight_g[g], p.ktab_g[g], p.out_g[g] = lg.weight.data_ptr(), lg.ktab.data_ptr(), out.data_ptr() + base * es_out
         split_ws = None
         if (getattr(layer, "split_k", 0) > 1 and self.split_k_on and residual is None and head is None and in2 is None and post is None
                 and n_dev is None and not out_f32 and out_geom is None and out_c_stride is None and N * Ho * Wo > 0):
@@ -253,7 +263,7 @@ class Engine:
             # the layer's, whatever the batch (dp_conv_params.split_k)
             split_ws = self._empty((layer.split_k, N * Ho * Wo, layer.cout), torch.float32)
             p.split_k, p.split_ws = layer.split_k, split_ws.data_ptr()
-        flops = 2 * (layer.macs_per_pixel + (head[2] if head is not None else 0)) * N * Ho * Wo
+        flops = 2 * (layer.macs_per_pixel + (head[2] if head is not None else 0)) * N * Ho * Wo * (len(groups) if groups is not None else 1)
         if self.prof is not None and N * Ho * Wo > 0:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
@@ -277,6 +287,9 @@ class Engine:
                 nbytes_in2 = N * Ho * Wo * in2.C * es
             nbytes = ((nbytes_in2 if in2 is not None else 0) + N * (H * W if s == 1 else Ho * Wo * min(layer.ntaps, s * s)) * x.C * es + layer.weight.numel() * es
                       + N * Ho * Wo * layer.cout * (es_out + (es if residual is not None else 0) // (4 if rshift else 1)))
+            if groups is not None:   # every group has its own weights and output; the input is read once
+                nbytes += (len(groups) - 1) * (layer.weight.numel() * es + N * Ho * Wo * layer.cout * es_out)
+                cls = cls[:-1] + ",x%d>" % len(groups) if cls.endswith(">") else cls
             if head is not None:   # the hidden tensor is never written; the head's 16 fp32 channels are
                 nbytes += N * Ho * Wo * (16 * 4 - layer.cout * es_out)
             if post is not None:
@@ -326,6 +339,21 @@ class Engine:
         p.hi_off, p.wi_off = layer.hi_off, layer.wi_off
         p.osN, p.osH, p.osW = x.H * x.W * layer.cout, x.W * layer.cout, layer.cout
         return self.lib.dp_conv2d_kernel_class(C.byref(p)) == 2
+
+    def groups_fusable(self, layer, x, n_dev=None):
+        """True when dp_conv2d_nhwc takes a grouped launch (dp_conv_params.n_groups) of this layer's shape on input x: the launch lands on
+        one of the 128-cout LDS-ring kernels (classes 3 / 4)."""
+        if not self.group_deconv:
+            return False
+        p = L.ConvParams()
+        p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout = x.N, x.H, x.W, x.C, x.H, x.W, layer.cout
+        p.Cout_w, p.Kpad, p.stride, p.ntaps, p.dtype = layer.cout_w, layer.kpad, layer.stride, layer.ntaps, self.dt
+        p.hi_off, p.wi_off, p.out_f32 = layer.hi_off, layer.wi_off, 1
+        p.osN, p.osH, p.osW = 1, 1, layer.cout          # (a pixel-shuffle output: not a plain NHWC tensor)
+        p.out = 1
+        if n_dev is not None:
+            p.n_dev = n_dev.data_ptr()
+        return layer.stride == 1 and self.lib.dp_conv2d_kernel_class(C.byref(p)) in (3, 4)
 
     def post_fusable(self, layer, x, post_mode):
         """True when dp_conv2d_nhwc can add a tensor after this layer's ReLU for input x (dp_conv_params.post_res: the
@@ -727,7 +755,13 @@ class Engine:
         Ci = self.model.iuv_c
         P2 = 2 * P
         low = self._empty((R, P2, P2, Ci), torch.float32)
-        for (a, b), layer in self.model.deconv.items():
+        items = list(self.model.deconv.items())
+        if self.groups_fusable(items[0][1], x, r_dev):
+            # the four parity classes in ONE launch (dp_conv_params.n_groups): same kernel and K order as the four launches, same bits
+            self.conv(items[0][1], x, out_f32=True, out=low, out_c_stride=Ci, out_geom=(P2 * P2 * Ci, 2 * P2 * Ci, 2 * Ci, 0), n_dev=r_dev,
+                      groups=[(layer, (a * P2 + b) * Ci) for (a, b), layer in items])
+            items = []
+        for (a, b), layer in items:
             # sub-pixel scatter: output pixel (2i + a, 2j + b)
             self.conv(layer, x, out_f32=True, out=low, out_c_stride=Ci,
                       out_geom=(P2 * P2 * Ci, 2 * P2 * Ci, 2 * Ci, (a * P2 + b) * Ci), n_dev=r_dev)

@@ -39,7 +39,8 @@ class ConvParams(C.Structure):
                 ("head_w", c_void_p), ("head_b", c_void_p), ("head_out", c_void_p),
                 ("shared_chip", c_i32), ("post_mode", c_i32), ("post_res", c_void_p), ("n_dev", c_void_p),
                 ("in2", c_void_p), ("H2", c_i32), ("W2", c_i32), ("Cin2", c_i32), ("stride2", c_i32),
-                ("split_k", c_i32), ("split_ws", c_void_p)]
+                ("split_k", c_i32), ("split_ws", c_void_p),
+                ("n_groups", c_i32), ("weight_g", c_void_p * 4), ("ktab_g", c_void_p * 4), ("out_g", c_void_p * 4)]
 
 
 class BottleneckParams(C.Structure):

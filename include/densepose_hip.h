@@ -153,6 +153,17 @@ typedef struct {
    * n_dev; anything else runs UNSPLIT on the kernel it would get without the field (no error). 0 or 1 = off. */
   int32_t split_k;
   void* split_ws;
+  /* Grouped launch (ABI 6): n_groups = 2 .. 4 convolutions that share the input, the bias, the geometry, the output strides and every
+   * other field run in ONE launch; group g multiplies by weight_g[g] (with tap table ktab_g[g]: same Kpad / ntaps) and stores at
+   * out_g[g] (`weight`, `ktab`, `out` are ignored). The chart predictor's ConvTranspose2d(k4, s2, p1) layers (chart.py:45-60) are four
+   * sub-pixel 2x2 convolutions - output pixel (2i + a, 2j + b) for (a, b) in {0, 1}^2 - whose separate launches each fill 1.5 rounds of
+   * the chip; as one launch the tiles of the four parity classes of a pixel tile sit side by side (same input rows, same XCD).
+   * Per-output arithmetic is that of the separate launch (same kernel, same K order): bit-identical. Kernel classes 3 / 4 (the 128-cout
+   * LDS-ring tiles) only, no residual / head / second source / post_res / split_k: DP_ERR_UNSUPPORTED otherwise. 0 or 1 = off. */
+  int32_t n_groups;
+  const void* weight_g[4];
+  const int32_t* ktab_g[4];
+  void* out_g[4];
 } dp_conv_params;
 int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
 /* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile,

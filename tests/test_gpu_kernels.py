@@ -850,6 +850,47 @@ def test_linear_and_deconv_forms(eng):
     assert torch.allclose(got, ref, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("ring2", [False, True])       # the 128x128 ring tile / the 256x128 two-workgroup tile (policy line lowered)
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+def test_deconv_parity_classes_in_one_launch(eng, dt, ring2, policy):
+    """The chart predictor's ConvTranspose2d layers (chart.py:45-60: 512 -> 2 + 25 + 25 + 25 channels, k4 s2 p1) on R ROI maps of
+    28 x 28: the four sub-pixel convolutions as ONE grouped launch (dp_conv_params.n_groups) against the four separate launches - bit
+    for bit, with a device-side live count, slots behind it untouched - and against torch's conv_transpose2d."""
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import deconv_parity_convs
+    e = eng[dt]
+    R, Cin, P, live = 11, 512, 28, 9
+    g = torch.Generator().manual_seed(77)
+    xi = torch.randn((R, Cin, P, P), generator=g)
+    ws = [torch.randn((Cin, c, 4, 4), generator=g) * (1.0 / (4 * Cin)) ** 0.5 for c in (2, 25, 25, 25)]
+    bs = [torch.randn((c,), generator=g) for c in (2, 25, 25, 25)]
+    if dt != "fp32":
+        xi, ws = _round(xi, dt), [_round(w, dt) for w in ws]
+    convs = deconv_parity_convs("d", [w.numpy() for w in ws], [b.numpy() for b in bs], Cin, e.dt, e.device)
+    items = list(convs.items())
+    Ci, P2 = items[0][1].cout, 2 * P
+    xa = Act(_nhwc(xi, Cin, e.tdt, e.device), R, P, P, Cin)
+    n_dev = torch.tensor([live], dtype=torch.int32, device=e.device)
+    policy.set("conv_ring2_m", 1 if ring2 else 0)
+    geom = lambda base: (P2 * P2 * Ci, 2 * P2 * Ci, 2 * Ci, base)      # noqa: E731
+    assert e.groups_fusable(items[0][1], xa, n_dev)
+    want = torch.full((R, P2, P2, Ci), 7.0, dtype=torch.float32, device=e.device)
+    for (a, b), l in items:
+        e.conv(l, xa, out_f32=True, out=want, out_c_stride=Ci, out_geom=geom((a * P2 + b) * Ci), n_dev=n_dev)
+    got = torch.full((R, P2, P2, Ci), 7.0, dtype=torch.float32, device=e.device)
+    e.conv(items[0][1], xa, out_f32=True, out=got, out_c_stride=Ci, out_geom=geom(0), n_dev=n_dev,
+           groups=[(l, (a * P2 + b) * Ci) for (a, b), l in items])
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert bool((got[live + 1:] == 7.0).all())     # (rows behind the count inside the last live tile are computed: dp_conv_params.n_dev)
+    ref = torch.cat([F.conv_transpose2d(xi.double(), w.double(), b.double(), stride=2, padding=1) for w, b in zip(ws, bs)], dim=1)
+    gd = got[:live, :, :, :77].cpu().permute(0, 3, 1, 2).double()
+    assert bool(((gd - ref[:live]).abs() <= 1e-5 * ref[:live].abs() + 2e-4).all()), float((gd - ref[:live]).abs().max())
+    # a layer the 128-cout ring kernels do not take (a single K plane on the generic kernel) refuses the grouped form
+    small = deconv_parity_convs("s", [ws[0][:8].numpy()], [bs[0].numpy()], 8, e.dt, e.device)
+    assert not e.groups_fusable(list(small.values())[0], Act(xa.t[..., :8].contiguous(), R, P, P, 8))
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 def test_pool_subsample_upsample(eng, dt):
     e = eng[dt]
