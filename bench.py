@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_DENSE = 2.5e15   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: "~2.5 PF dense")
 PEAK_F32_MATRIX = 157.3e12
+PEAK_HBM = 8.0e12          # HBM3E, bytes/s (MI355X_MICROARCH.md: 8 TB/s spec, 6.3 TB/s measured with a float4 copy)
 HBM_PEAK = 8.0e12
 
 
@@ -175,14 +176,21 @@ def r_sensitivity(args, state, frames, device):
     return out
 
 
-def multi_gpu_record(values, world, device):
+def multi_gpu_record(values, world, device, extra=None):
     """`multi_gpu` of the JSON line: what every rank measured for itself, as MIN / MAX / per-rank lists (the driver computes scaling
     efficiency from `value`; this says WHERE a shortfall comes from - the host feed path or the GPUs)."""
     from densepose_torchscript_amd.parallel import rank_stats
     import torch.distributed as dist
     stats = rank_stats(values, device)
+    info = None
+    if extra is not None:      # per-rank strings (device name, CPU share): one all_gather_object
+        info = [None] * (dist.get_world_size() if dist.is_initialized() else 1)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_gather_object(info, extra)
+        else:
+            info = [extra]
     return {"ranks_in_process_group": dist.get_world_size() if dist.is_initialized() else 1, "world": world,
-            "backend": dist.get_backend() if dist.is_initialized() else None, **stats,
+            "backend": dist.get_backend() if dist.is_initialized() else None, **stats, **({"per_rank_info": info} if info else {}),
             "note": "sustained / host_frames: every rank runs the loop at the same time (frames resident in HBM / starting in pageable host "
                     "memory on every rank at once); weight_broadcast: the one RCCL broadcast of the packed weights from rank 0"}
 
@@ -198,8 +206,11 @@ def spawn_selftest():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
     # the multi-rank part of the benchmark record, with stand-in numbers: same keys, same collective (parallel.rank_stats)
+    cpus = parallel.pin_rank_to_cpus()
     multi = multi_gpu_record({"sustained_images_per_s": 100.0 + rank, "host_frames_images_per_s": 90.0 - rank,
-                              "weight_broadcast_s": 0.01 * (rank + 1), "weight_broadcast_bytes": 1.0e6}, world, None)
+                              "weight_broadcast_s": 0.01 * (rank + 1), "weight_broadcast_bytes": 1.0e6}, world, None,
+                             extra={"rank": rank, "device": "selftest", "local_rank": local_rank, "cpus": (len(cpus) if cpus else None),
+                                    "first_cpu": (cpus[0] if cpus else None), "host_gather_workers": parallel.host_workers(4)})
     if rank == 0:
         print(json.dumps({"selftest": "spawn", "world": world, "max_over_ranks": float(t.item()), "multi_gpu": multi}), flush=True)
     if world > 1:
@@ -243,6 +254,9 @@ def main():
     from densepose_torchscript_amd.weights import param_shapes
     import torch.distributed as dist
 
+    # a rank's host threads stay on its share of the CPUs (in-process sched_setaffinity, BEFORE the process group / the GPU context
+    # spawn their helper threads, which inherit the mask)
+    rank_cpus = parallel.pin_rank_to_cpus()
     rank, local_rank, world = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
@@ -335,7 +349,10 @@ def main():
     if world > 1:
         multi = multi_gpu_record({"sustained_images_per_s": sustained["images_per_s"] if sustained else 0.0,
                                   "host_frames_images_per_s": host_rate["images_per_s"] if host_rate else 0.0,
-                                  "weight_broadcast_s": bcast_s, "weight_broadcast_bytes": float(bcast_bytes)}, world, device)
+                                  "weight_broadcast_s": bcast_s, "weight_broadcast_bytes": float(bcast_bytes)}, world, device,
+                                 extra={"rank": rank, "device": torch.cuda.get_device_name(local_rank), "local_rank": local_rank,
+                                        "cpus": (len(rank_cpus) if rank_cpus else None), "first_cpu": (rank_cpus[0] if rank_cpus else None),
+                                        "host_gather_workers": parallel.host_workers(4)})
     pred.pipeline_depth = 1   # the latency loop and the roofline pass below run batch after batch on one stream
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -386,11 +403,12 @@ def main():
     stages = eng.trace.summary()
     eng.trace = None
     agg = {}
-    for cls, flops, e0, e1, name, _ in eng.prof:
-        a = agg.setdefault(cls, [0, 0.0, 0])
+    for cls, flops, e0, e1, name, nbytes in eng.prof:
+        a = agg.setdefault(cls, [0, 0.0, 0, 0])
         a[0] += flops
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
+        a[3] += nbytes
     eng.prof = None
     pred.num_streams, eng.use_graphs, eng.overlap_decoder = args.streams, not args.no_graphs, overlap
     dom = max(agg, key=lambda c: agg[c][1])
@@ -443,6 +461,18 @@ def main():
         ff, ft, fc = sum(v[0] for v in fam), sum(v[1] for v in fam), sum(v[2] for v in fam)
         roofline["wsr_family"] = {"tflops": round(ff / ft / 1e12, 2), "frac": round(ff / ft / peak, 4), "calls_per_step": fc // args.steps,
                                   "ms_per_step": round(1e3 * ft / args.steps, 3)}
+
+    # the kernel classes whose roof is HBM (pointwise / fused-bottleneck / stem layers: a few FLOP per byte): ALGORITHMIC bytes (input +
+    # output + residual + weights, each once) per second of the same event-timed launches, against 8 TB/s - so that the line shows
+    # which part of the backbone sits at its roof (the practical ceiling of a streaming kernel on this chip is 5.5 - 6.3 TB/s) and
+    # which part is far from either roof
+    hbm = {}
+    for c, v in agg.items():
+        if c.startswith(("conv1x1_stream_kernel", "bottleneck_tail64_kernel", "stem_pool_kernel", "conv1x1_pws_kernel")) and v[1] > 0:
+            hbm[c] = {"bound": "hbm", "achieved": round(v[3] / v[1] / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(v[3] / v[1] / PEAK_HBM, 4),
+                      "alg_mb_per_step": round(v[3] / args.steps / 1e6, 1), "ms_per_step": round(1e3 * v[1] / args.steps, 3), "calls_per_step": v[2] // args.steps,
+                      "tflops": round(v[0] / v[1] / 1e12, 1)}
+    roofline["hbm_bound_classes"] = hbm
 
     result = None
     if rank == 0:

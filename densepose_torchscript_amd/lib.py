@@ -283,6 +283,13 @@ class policy:
         return False
 
 
+def apply_env_policy():
+    """tools/: os.environ changed at run time -> policy table (every key back to its default first). The library never looks itself."""
+    lib = load()
+    lib.dp_reset_policy()
+    _apply_env_policy(lib)
+
+
 def _apply_env_policy(lib):
     """The library itself never reads the environment. For the command-line tools (tools/*.sh A/B runs: `DP_CONV_WS=0 python bench.py`)
     the HOST side applies DP_<KEY> variables to the policy table once, when the library is loaded."""

@@ -29,6 +29,93 @@ def init_distributed(backend=None):
     return rank, local_rank, world
 
 
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(local_rank, sysfs="/sys"):
+    """CPUs of the NUMA node GPU `local_rank` hangs off: the local_rank-th render device in PCI-address order
+    (/sys/class/drm/card*/device/numa_node -> /sys/devices/system/node/node<N>/cpulist). None when sysfs does not say
+    (numa_node = -1 on single-node hosts, containers without the files)."""
+    import glob
+    cards = []
+    for dev in glob.glob(os.path.join(sysfs, "class/drm/card[0-9]*/device")):
+        try:
+            if not os.path.exists(os.path.join(dev, "numa_node")):
+                continue
+            vendor = open(os.path.join(dev, "vendor")).read().strip() if os.path.exists(os.path.join(dev, "vendor")) else ""
+            if vendor not in ("0x1002", ""):       # AMD GPUs only (a BMC's VGA function has a card node too)
+                continue
+            cards.append((os.path.realpath(dev), dev))
+        except OSError:
+            continue
+    cards.sort()
+    if local_rank >= len(cards):
+        return None
+    try:
+        node = int(open(os.path.join(cards[local_rank][1], "numa_node")).read().strip())
+        if node < 0:
+            return None
+        return _parse_cpulist(open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)).read()) or None
+    except (OSError, ValueError):
+        return None
+
+
+def plan_rank_cpus(local_rank, local_world, allowed, numa_cpus=None):
+    """The host CPUs rank `local_rank` of `local_world` on this node may run on: its GPU's NUMA node's CPUs (when known) restricted
+    to what the process is allowed, split evenly among the ranks that share that node - or, without NUMA information, an even
+    contiguous split of the allowed CPUs. Never empty: a share smaller than one CPU falls back to the whole allowed set."""
+    allowed = sorted(allowed)
+    pool = sorted(set(allowed) & set(numa_cpus)) if numa_cpus else allowed
+    if not pool:
+        pool = allowed
+    # ranks that share this pool: without per-rank NUMA knowledge of the others, assume the ranks are spread evenly over the pools
+    n_pools = max(1, len(allowed) // max(len(pool), 1))
+    sharers = max(1, -(-local_world // n_pools))
+    idx = local_rank % sharers if numa_cpus else local_rank
+    if not numa_cpus:
+        sharers = local_world
+    per = len(pool) // sharers
+    if per < 1:
+        return allowed
+    return pool[idx * per:(idx + 1) * per]
+
+
+def pin_rank_to_cpus(local_rank=None, local_world=None):
+    """Pin THIS process (in place: os.sched_setaffinity - no taskset / numactl hop, which on a GPU box would be an exec in front of a
+    process that may already hold the GPU) to its share of the host CPUs and size torch's intra-op pool to it. 8 ranks on a
+    256-thread host otherwise each start as many OpenMP / gather threads as there are CPUs and migrate freely across sockets; the
+    `multi_gpu` record of bench.py would show the slow rank but nothing would prevent it. Returns the CPU list (None = not applied:
+    single rank, or a platform without sched_setaffinity)."""
+    _, lr, _ = env_rank()
+    local_rank = lr if local_rank is None else local_rank
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) if local_world is None else local_world
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    cpus = plan_rank_cpus(local_rank, local_world, allowed, gpu_numa_cpus(local_rank))
+    os.sched_setaffinity(0, cpus)
+    torch.set_num_threads(max(1, min(len(cpus), 16)))
+    return cpus
+
+
+def host_workers(default=4):
+    """Worker threads of a rank's host-side frame gather (predictor._HostFrameRing): the single-process default divided among the
+    ranks of this node, at least one."""
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    try:
+        n_cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_cpus = os.cpu_count() or 1
+    return max(1, min(default, n_cpus, max(1, (default * 2) // max(local_world, 1)) if local_world > 1 else default))
+
+
 def shard_range(n_items, rank, world):
     """Contiguous shard [lo, hi) of n_items frames for this rank (sizes differ by at most one)."""
     base, rem = divmod(n_items, world)

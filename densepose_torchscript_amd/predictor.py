@@ -29,7 +29,11 @@ class _HostFrameRing:
     `slots` buffers per frame geometry rotate; a slot is rewritten only after its previous upload has completed (host wait on
     its event, normally long past) and its device landing buffer only after the resize kernel that read it has run."""
 
-    def __init__(self, device, copy_stream, slots=3, workers=4):
+    def __init__(self, device, copy_stream, slots=3, workers=None):
+        if workers is None:      # a rank of a multi-GPU run gets its share of the host, not the single-process default
+            from .parallel import host_workers
+            workers = host_workers(4)
+        self.workers = workers
         self.device, self.n_slots = device, slots
         self.copy_stream = copy_stream
         self.rings = {}      # (n, frame shape) -> [slot dicts]

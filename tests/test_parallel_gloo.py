@@ -96,6 +96,8 @@ def test_bench_self_launch_spawns_ranks_over_gloo():
         assert set(m[key]) == {"min", "max", "per_rank"} and len(m[key]["per_rank"]) == 2
         assert m[key]["min"] == min(m[key]["per_rank"]) and m[key]["max"] == max(m[key]["per_rank"])
     assert m["sustained_images_per_s"]["per_rank"] == [100.0, 101.0] and m["host_frames_images_per_s"]["per_rank"] == [90.0, 89.0]
+    info = m["per_rank_info"]          # who ran where: rank, device name, CPU share, gather workers - one entry per rank, in rank order
+    assert [i["rank"] for i in info] == [0, 1] and all(i["device"] == "selftest" and i["host_gather_workers"] >= 1 for i in info)
 
 
 def test_bench_self_launch_propagates_rank_failure():
@@ -120,3 +122,79 @@ def test_launch_local_ranks_stops_peers_when_one_rank_fails(tmp_path):
     t0 = time.time()
     rc = launch_local_ranks([str(script)], 3)
     assert rc == 7 and time.time() - t0 < 30
+
+
+BCAST_WORKER = textwrap.dedent("""
+    import hashlib, os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    from densepose_torchscript_amd import TINY_OPTS, get_config, make_synthetic_state, parallel
+    from densepose_torchscript_amd import lib as L
+    from densepose_torchscript_amd.pack import PackedModel
+    from densepose_torchscript_amd.weights import param_shapes
+    cpus = parallel.pin_rank_to_cpus()
+    rank, local_rank, world = parallel.init_distributed(backend="gloo")
+    cfg = get_config("densepose_rcnn_R_50_FPN_DL_s1x", TINY_OPTS)
+    # bench.py's start-up: rank 0 owns the weights, every other rank packs a zeros / unit-variance state of the same shapes
+    if rank == 0:
+        state = make_synthetic_state(cfg, 3)
+    else:
+        state = {k: np.zeros(s, dtype=np.float32) for k, s in param_shapes(cfg).items()}
+        for k in state:
+            if k.endswith("running_var"):
+                state[k] += 1.0
+    model = PackedModel(cfg, state, L.DP_BF16, "cpu")      # the host-side packer (dp_pack_conv_weights); tensors stay on the CPU for gloo
+    tensors = model.parameter_tensors()
+    digest = lambda ts: hashlib.sha256(b"".join(t.contiguous().view(torch.uint8).numpy().tobytes() for t in ts)).hexdigest()
+    before = digest(tensors)
+    parallel.broadcast_tensors(tensors, src=0, bucket_bytes=1 << 20)      # the REAL collective, several buckets per dtype
+    after = digest(tensors)
+    both = [None, None]
+    dist.all_gather_object(both, (rank, before, after, None if cpus is None else len(cpus)))
+    assert both[0][2] == both[1][2], "rank 1 does not hold rank 0's packed blob after the broadcast"
+    assert both[0][1] == both[0][2], "the source rank's tensors changed"
+    assert both[1][1] != both[1][2], "rank 1 started from the same values: the test proves nothing"
+    dtypes = sorted({str(t.dtype) for t in tensors})
+    assert "torch.bfloat16" in dtypes and "torch.float32" in dtypes and "torch.int32" in dtypes, dtypes
+    if cpus is not None:
+        assert set(cpus) <= set(os.sched_getaffinity(0)) and len(os.sched_getaffinity(0)) == len(cpus)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok", len(tensors), "tensors", dtypes, "cpus", None if cpus is None else len(cpus))
+""")
+
+
+def test_weight_broadcast_reproduces_rank0_blob_over_gloo(tmp_path):
+    """The multi-GPU start-up of bench.py with the REAL collective (gloo here, RCCL on the GPU box): a non-zero rank packs a zero state
+    and receives PackedModel.parameter_tensors() - bf16 weight matrices, int32 tap tables, fp32 biases / GroupNorm parameters - through
+    parallel.broadcast_tensors in several buckets per dtype; afterwards it holds rank 0's packed blob byte for byte. Each rank pins
+    itself to its share of the host CPUs first (parallel.pin_rank_to_cpus: in-process sched_setaffinity)."""
+    script = tmp_path / "bcast_worker.py"
+    script.write_text(BCAST_WORKER % ROOT)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
+
+
+def test_rank_cpu_plan():
+    """parallel.plan_rank_cpus: disjoint, non-empty shares; the NUMA node of the rank's GPU when sysfs knows it; never outside the
+    process's allowed set; a host with fewer CPUs than ranks keeps everything allowed."""
+    from densepose_torchscript_amd.parallel import _parse_cpulist, gpu_numa_cpus, host_workers, plan_rank_cpus
+    assert _parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    allowed = list(range(256))
+    shares = [plan_rank_cpus(r, 8, allowed) for r in range(8)]           # no NUMA information: an even contiguous split
+    assert all(len(s) == 32 for s in shares) and sorted(c for s in shares for c in s) == allowed
+    node0, node1 = list(range(0, 64)) + list(range(128, 192)), list(range(64, 128)) + list(range(192, 256))
+    shares = [plan_rank_cpus(r, 8, allowed, node0 if r < 4 else node1) for r in range(8)]      # 2 sockets x 4 GPUs
+    assert all(len(s) == 32 for s in shares) and sorted(c for s in shares for c in s) == allowed
+    assert all(set(shares[r]) <= set(node0 if r < 4 else node1) for r in range(8))
+    assert plan_rank_cpus(1, 2, [4, 5, 6, 7], numa_cpus=[0, 1, 2, 3]) in ([4, 5, 6, 7], [6, 7])    # NUMA list outside the cgroup: ignored
+    assert plan_rank_cpus(5, 8, [0, 1, 2]) == [0, 1, 2]                  # fewer CPUs than ranks: no pinning below one CPU
+    assert gpu_numa_cpus(0, sysfs="/nonexistent") is None
+    assert host_workers(4) >= 1

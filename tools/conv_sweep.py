@@ -25,6 +25,7 @@ for N, Cin, H, W, Cout, k, name in shapes:
     res = []
     for force in ("0", "1", "3", "2"):
         os.environ["DP_CONV_BIG"] = force
+        from densepose_torchscript_amd import lib as _L; _L.apply_env_policy()
         for _ in range(2): e.conv(layer, x, relu=True, out=out)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): e.conv(layer, x, relu=True, out=out)

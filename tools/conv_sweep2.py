@@ -5,6 +5,7 @@ import numpy as np, torch, time
 from densepose_torchscript_amd import TINY_OPTS, get_config, make_synthetic_state
 from densepose_torchscript_amd.engine import Engine, Act
 from densepose_torchscript_amd.pack import conv_from_oihw
+from densepose_torchscript_amd import lib as _L   # the library reads no environment: apply_env_policy() after every change
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 cfg = get_config("densepose_rcnn_R_50_FPN_s1x", TINY_OPTS)
 e = Engine(cfg, make_synthetic_state(cfg, 0), dtype="bf16")
@@ -20,8 +21,8 @@ shapes = [  # N, Cin, H, W, Cout, k, name
     (B, 512, 25, 42, 2048, 1, "res5 conv3"), (B, 64, 200, 336, 64, 1, "res2.0 conv1"), (B, 64, 200, 336, 256, 1, "res2 conv3-type"),
 ]
 VAR = {"default": {}, "generic": {"DP_CONV_BIG": "0"}, "ring256": {"DP_CONV_BIG": "1"}, "ring256x128": {"DP_CONV_BIG": "3"}, "ring128": {"DP_CONV_BIG": "2"},
-       "stream": {"DP_CONV_BIG": "5"}, "no-ws/rows": {"DP_CONV_WS": "0", "DP_CONV_ROWS": "0"}}
-KEYS = ("DP_CONV_BIG", "DP_CONV_WS", "DP_CONV_ROWS")
+       "stream": {"DP_CONV_BIG": "5"}, "no-ws/rows/pws": {"DP_CONV_WS": "0", "DP_CONV_ROWS": "0", "DP_CONV_PWS": "0"}}
+KEYS = ("DP_CONV_BIG", "DP_CONV_WS", "DP_CONV_ROWS", "DP_CONV_PWS")
 g = torch.Generator().manual_seed(0)
 def run(layer, x, out, n):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,8 +43,10 @@ for N, Cin, H, W, Cout, k, name in shapes:
         for v, env in VAR.items():
             for kk in KEYS: os.environ.pop(kk, None)
             os.environ.update(env)
+            _L.apply_env_policy()
             res[v].append(run(layer, x, out, 50))
     for kk in KEYS: os.environ.pop(kk, None)
+    _L.apply_env_policy()
     med = {v: sorted(t)[1] for v, t in res.items()}
     best = min(med, key=med.get)
     fl = 2.0 * N * H * W * Cout * Cin * k * k

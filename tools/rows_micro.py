@@ -33,6 +33,7 @@ def setmode(name):
     for k in ("DP_CONV_ROWS", "DP_CONV_ROWS2", "DP_CONV_ROWS2_LOCKSTEP", "DP_CONV_ROWS_CHAIN", "DP_CONV_ROWS2_256"):
         os.environ.pop(k, None)
     os.environ.update(MODES[name])
+    from densepose_torchscript_amd import lib as _L; _L.apply_env_policy()   # the library reads no environment: the host applies it
 # the chip's clock settles over hundreds of milliseconds: 1.5 s of the same load first, then the modes in turn, three passes
 setmode(names[0])
 import time

@@ -20,6 +20,7 @@ def run(layer, x, out, n):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 os.environ["DP_CONV_WS"] = "0"; os.environ["DP_CONV_BIG"] = "1"
+from densepose_torchscript_amd import lib as _L; _L.apply_env_policy()   # the library reads no environment
 for N, Cin, H, W, Cout, k, name in shapes:
     w = (torch.randn((Cout, Cin, k, k), generator=g) * 0.05).numpy()
     layer = conv_from_oihw("m", w, np.zeros(Cout, np.float32), Cin, 1, k // 2, 1, e.dt, e.device)
@@ -33,6 +34,7 @@ for N, Cin, H, W, Cout, k, name in shapes:
         for v in var:
             os.environ.pop("DP_CONV_TP", None)
             if v != "auto": os.environ["DP_CONV_TP"] = v
+            _L.apply_env_policy()
             res[v].append(run(layer, x, out, 50))
     os.environ.pop("DP_CONV_TP", None)
     med = {v: sorted(t)[1] for v, t in res.items()}

@@ -16,6 +16,7 @@ for C in (256, 128):
         for ws in ("1", "0"):
             os.environ["DP_CONV_WS"] = ws
             os.environ["DP_WS_MIN_M"] = "1"
+            from densepose_torchscript_amd import lib as _L; _L.apply_env_policy()
             outs[ws] = e.conv(layer, x, relu=True).t.clone()
         torch.cuda.synchronize()
         d = (outs["1"].float() - outs["0"].float()).abs()
