@@ -41,9 +41,10 @@ def cpu_baseline(cfg, state, hw, budget_s):
     sample of the same workload (same weights, same frames, same R): 3 warm-up frames, then 10 timed ones,
     fewer only if the box is so slow that 10 would not fit the budget."""
     from oracle.ref_cpu import OracleModel
-    # torch's CPU convolutions stop scaling (and then collapse) beyond ~32 threads on this class of host
-    # (measured on the 2x64-core EPYC GPU box: 3x3 conv 256->256 @200x336: 61 ms at 32 threads, 149 ms at 128, 595 ms at 256)
-    cores = min(os.cpu_count() or 1, 32)
+    # torch's CPU convolutions stop scaling (and then collapse) beyond a few dozen threads on this class of host: the whole path at
+    # 8 / 16 / 32 / 64 threads of the 256-CPU GPU box runs at 0.73 / 0.88 / 0.67 / 0.33 images/s, nproc does not finish a frame in a
+    # minute (tools/cpu_threads.py, profiles/r5_cpu_threads.txt) - the baseline is timed at the thread count that serves it best
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     model = OracleModel(cfg, state)
@@ -412,7 +413,7 @@ def main():
     eng.prof = None
     pred.num_streams, eng.use_graphs, eng.overlap_decoder = args.streams, not args.no_graphs, overlap
     dom = max(agg, key=lambda c: agg[c][1])
-    dflops, dsec, dcalls = agg[dom]
+    dflops, dsec, dcalls = agg[dom][:3]
     peak = PEAK_F32_MATRIX if args.dtype == "fp32" else PEAK_BF16_DENSE  # fp16 and bf16 MFMA share the dense peak
     traffic = None
     for tname in sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json"))), reverse=True):   # newest committed PMC summary that has this kernel
@@ -468,7 +469,7 @@ def main():
     # which part is far from either roof
     hbm = {}
     for c, v in agg.items():
-        if c.startswith(("conv1x1_stream_kernel", "bottleneck_tail64_kernel", "stem_pool_kernel", "conv1x1_pws_kernel")) and v[1] > 0:
+        if c.startswith(("conv1x1_stream_kernel", "bottleneck_tail64_kernel", "stem_pool_kernel", "conv1x1_pws_kernel", "conv1x1_pwq_kernel")) and v[1] > 0:
             hbm[c] = {"bound": "hbm", "achieved": round(v[3] / v[1] / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(v[3] / v[1] / PEAK_HBM, 4),
                       "alg_mb_per_step": round(v[3] / args.steps / 1e6, 1), "ms_per_step": round(1e3 * v[1] / args.steps, 3), "calls_per_step": v[2] // args.steps,
                       "tflops": round(v[0] / v[1] / 1e12, 1)}

@@ -447,6 +447,198 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pws_kernel(const PwsArgs p) {
 #undef DP_STAMP
 }
 
+// =====================================================================================================
+// K = 256 channels (conv3 of res4: 256 -> 1024 + residual + ReLU, resnet.py:199-205 - five launches for R50, twenty-two for R101). The
+// same scheme with the register budget cut the other way: a wave keeps 64 couts x 256 K (4 MFMA row tiles x 8 K steps = the same 32
+// fragments), the eight waves are eight cout sub-slices of one K slice - no exchange - and a workgroup covers 512 couts. A pixel row is
+// 512 bytes: one LDS-DMA piece carries two of them, a step's stage is 16 KiB. On the streaming kernel (weights in LDS, pixel fragments
+// from global memory, one wave per SIMD) the layer ran at 3.3 - 3.6 TB/s of its algorithmic bytes with all of them in the Infinity Cache.
+// =====================================================================================================
+struct PwqCfg {
+  static constexpr int CW = 512, P = 32, PT = 2, KC = 8, NT = 4, RB = 512;     // couts / pixels per step / pixel tiles / K steps / cout tiles / row bytes
+  static constexpr int STAGE_B = P * RB;                                       // 16 KiB
+  static constexpr int WSCR = 2 * STAGE_B;
+  static constexpr int LDS = WSCR + 8 * 8192;
+};
+
+template <typename T, bool HAS_RES>
+__global__ __launch_bounds__(512, 2) void conv1x1_pwq_kernel(const PwsArgs p) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int CW = PwqCfg::CW, P = PwqCfg::P, PT = PwqCfg::PT, KC = PwqCfg::KC, NT = PwqCfg::NT, RB = PwqCfg::RB, STAGE_B = PwqCfg::STAGE_B;
+  constexpr int OOB = (int)0x80000000;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.x;
+  const int slice = (b >> 3) % p.n_slices;
+  const int pg = (b & 7) + 8 * (b / (8 * p.n_slices));
+  const int s_begin = (int)((long long)p.S * pg / p.n_pg), s_end = (int)((long long)p.S * (pg + 1) / p.n_pg);
+  const int nst = s_end - s_begin;
+  if (nst <= 0) return;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_RES ? p.res : p.in), 0, HAS_RES ? p.res_bytes : 0u, 0x00020000);
+
+  // piece j of this wave = pixels 2 (2 wave + j), + 1 of the step (two 512-byte rows per KiB): lane l -> pixel + (l >> 5), position l & 31,
+  // which holds chunk (l & 31) ^ (pixel & 15)
+  auto issue_piece = [&](int s, auto jj) __attribute__((always_inline)) {
+    constexpr int j = decltype(jj)::value;
+    const int m0 = s < nst ? (s_begin + s) * P : p.M;
+    const int q = (wave * 2 + j) * 2 + (lane >> 5);
+    const int m = m0 + q;
+    const int off = m < p.M ? m * RB + (((lane & 31) ^ (q & 15)) << 4) : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(smem + (s & 1) * STAGE_B + (wave * 2 + j) * 1024), 16, off, 0, 0, 0);
+  };
+  issue_piece(0, std::integral_constant<int, 0>{});
+  issue_piece(0, std::integral_constant<int, 1>{});
+
+  // ---- weights: cout sub-slice `wave` (64 couts = physical tiles cbase / 16 .. + 3 of the packed matrix) x 8 K planes, through LDS
+  const int cbase = slice * CW + wave * 64;
+  u32x4 wfr[32];
+  {
+    const int n_planes = p.kpad * 2 / 64;
+    unsigned char* const scr = smem + PwqCfg::WSCR + wave * 8192;
+    const int lrow = lane >> 2;
+    const unsigned char* __restrict__ wsrc = reinterpret_cast<const unsigned char*>(p.w) + lrow * 64 + (((lane & 3) ^ swz(lrow)) << 4);
+    const unsigned char* const rd = scr + fr * 64 + ((fq ^ swz(fr)) << 4);
+    auto issue_round = [&](auto rr) __attribute__((always_inline)) {
+      constexpr int r = decltype(rr)::value;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = r * 4 + j, t = k / KC, c = k % KC;
+        const long long tile = (long long)((cbase >> 4) + t) * n_planes + c;
+        __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(wsrc + tile * 1024), DP_LDS_PTR(scr + (r & 1) * 4096 + j * 1024), 16, 0, 0);
+      }
+    };
+    issue_round(std::integral_constant<int, 0>{});
+    issue_round(std::integral_constant<int, 1>{});
+    static_for<0, 8>([&](auto rr) {
+      constexpr int r = decltype(rr)::value;
+      if constexpr (r < 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wfr[r * 4 + j] = *reinterpret_cast<const u32x4*>(rd + (r & 1) * 4096 + j * 1024);
+      if constexpr (r + 2 < 8) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_round(std::integral_constant<int, (r + 2 < 8 ? r + 2 : 0)>{});
+      }
+    });
+  }
+  // bias = initial accumulator value: tile t, rows 4 fq .. + 3 = couts cbase + (t >> 1) * 32 + fq * 8 + (t & 1) * 4 + e
+  f32x4 bias_t[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bias_t[t] = *reinterpret_cast<const f32x4*>(p.bias + cbase + (t >> 1) * 32 + fq * 8 + (t & 1) * 4);
+  const int opix = p.cout * 2;
+  int fo[4];
+#pragma unroll
+  for (int cl = 0; cl < 4; ++cl) fo[cl] = fr * RB + ((cl ^ (fr >> 2)) << 6) + ((fq ^ (fr & 3)) << 4);
+
+  f32x4 acc[PT][NT];
+  u32x4 rv[PT][2];
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    rv[pt][0] = rv[pt][1] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[pt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto finalize = [&](int s) __attribute__((always_inline)) {
+    const int m0 = (s_begin + s) * P;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = acc[pt][2 * h][k]; v[4 + k] = acc[pt][2 * h + 1][k]; }
+        if constexpr (HAS_RES) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            v[2 * k] += Elem<T>::unpack(rv[pt][h][k] & 0xffffu);
+            v[2 * k + 1] += Elem<T>::unpack(rv[pt][h][k] >> 16);
+          }
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        const int m = m0 + pt * 16 + fr;
+        const int off = (s >= 0 && m < p.M) ? m * opix + (cbase + h * 32 + fq * 8) * 2 : OOB;
+        const u32x4 pk = {Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3]), Elem<T>::pack2(v[4], v[5]), Elem<T>::pack2(v[6], v[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, off, 0, 0);
+      }
+  };
+  auto res_issue = [&](int s) __attribute__((always_inline)) {
+    const int m0 = s < nst ? (s_begin + s) * P : p.M;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int m = m0 + pt * 16 + fr;
+        rv[pt][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, m < p.M ? m * opix + (cbase + h * 32 + fq * 8) * 2 : OOB, 0, 0);
+      }
+  };
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __builtin_amdgcn_s_barrier();
+
+  constexpr int AHEAD = 4, NF = KC * PT;
+  for (int i = 0; i <= nst; ++i) {
+    finalize(i - 1);
+    if constexpr (HAS_RES) res_issue(i);
+    __builtin_amdgcn_sched_barrier(0);
+    if (i < nst) {
+      const int sb = (i & 1) * STAGE_B;
+      int va[4];
+#pragma unroll
+      for (int cl = 0; cl < 4; ++cl) va[cl] = sb + fo[cl];
+      auto frag_at = [&](auto ff) __attribute__((always_inline)) -> u32x4 {
+        constexpr int f = decltype(ff)::value;
+        constexpr int c = f / PT, pt = f % PT;
+        return *reinterpret_cast<const u32x4*>(smem + va[c & 3] + (pt * 16 * RB + (c >> 2) * 256));
+      };
+      u32x4 bf[AHEAD + 1];
+      static_for<0, AHEAD>([&](auto ff) { bf[decltype(ff)::value] = frag_at(ff); });
+#pragma unroll
+      for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[pt][t] = bias_t[t];
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, NF>([&](auto ff) {
+        constexpr int f = decltype(ff)::value;
+        constexpr int c = f / PT, pt = f % PT;
+        if constexpr (f + AHEAD < NF) bf[(f + AHEAD) % (AHEAD + 1)] = frag_at(std::integral_constant<int, (f + AHEAD < NF ? f + AHEAD : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) Mma<T>::run(wfr[t * KC + c], bf[f % (AHEAD + 1)], acc[pt][t]);
+        // the two pieces of step i + 1 go out between the MFMA groups of the first half of the phase
+        if constexpr (f == 1) issue_piece(i + 1, std::integral_constant<int, 0>{});
+        if constexpr (f == 5) issue_piece(i + 1, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+template <typename T, bool HAS_RES>
+int launch_pwq_r(PwsArgs a, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_pwq_kernel<T, HAS_RES>), hipFuncAttributeMaxDynamicSharedMemorySize, PwqCfg::LDS);
+    attr_set = true;
+  }
+  a.S = (a.M + PwqCfg::P - 1) / PwqCfg::P;
+  a.n_slices = a.cout / PwqCfg::CW;
+  int groups = pws_num_cus() / (8 * a.n_slices);
+  if (groups < 1) groups = 1;
+  a.n_pg = groups * 8;
+  a.dbg = nullptr;
+  hipLaunchKernelGGL((conv1x1_pwq_kernel<T, HAS_RES>), dim3(a.n_pg * a.n_slices), dim3(512), PwqCfg::LDS, stream, a);
+  return dp_check_launch("conv1x1_pwq_kernel");
+}
+
 template <typename T, int SK, bool HAS_RES, bool SKEW>
 int launch_pws_r(PwsArgs a, hipStream_t stream) {
   using Cfg = PwsCfg<T, SK>;
@@ -510,15 +702,15 @@ int launch_pws(const PwsArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-// used by dp_conv2d_nhwc (dp_conv.hip): a pointwise stride-1 layer with K = 512 / 1024 / 2048 channels whose cout count is a whole number
-// of workgroup slices (256 / 128 / 64), plain NHWC output, optional residual (plain NHWC of the output's shape, or the half-size top-down
+// used by dp_conv2d_nhwc (dp_conv.hip): a pointwise stride-1 layer with K = 256 / 512 / 1024 / 2048 channels whose cout count is a whole
+// number of workgroup slices (512 / 256 / 128 / 64), plain NHWC output, optional residual (plain NHWC of the output's shape, or the half-size top-down
 // map of the FPN read through a nearest x2 up-sampling). No size threshold: the summation order is this kernel's own.
 bool dp_conv_pws_ok(const dp_conv_params* p) {
   if (dp_policy().conv_pws == 0) return false;
   if (!(p->dtype == DP_BF16 || p->dtype == DP_F16)) return false;
   const int sk = p->Cin == 512 ? 1 : (p->Cin == 1024 ? 2 : (p->Cin == 2048 ? 4 : 0));
-  if (sk == 0) return false;
-  const int cw = 256 / sk;
+  if (sk == 0 && p->Cin != 256) return false;
+  const int cw = p->Cin == 256 ? 512 : 256 / sk;      // 256 channels: the 64-couts-per-wave form (conv1x1_pwq_kernel)
   const long long M = (long long)p->N * p->Ho * p->Wo;
   const bool lin_out = p->osW == p->Cout && p->osH == (long long)p->Wo * p->osW && p->osN == (long long)p->Ho * p->osH;
   const bool lin_res = !p->residual || (p->rshift == 0 && p->rsW == p->Cout && p->rsH == (long long)p->Wo * p->rsW && p->rsN == (long long)p->Ho * p->rsH);
@@ -545,6 +737,10 @@ int dp_conv_pws_launch(const dp_conv_params* p, dp_stream_t stream) {
   a.rsN = (int)p->rsN; a.rsH = (int)p->rsH; a.rsW = (int)p->rsW;
   hipStream_t s = as_stream(stream);
   const bool bf = p->dtype == DP_BF16;
+  if (p->Cin == 256) {
+    if (a.res) return bf ? launch_pwq_r<uint16_t, true>(a, s) : launch_pwq_r<f16_t, true>(a, s);
+    return bf ? launch_pwq_r<uint16_t, false>(a, s) : launch_pwq_r<f16_t, false>(a, s);
+  }
   if (p->Cin == 512) return bf ? launch_pws<uint16_t, 1>(a, s) : launch_pws<f16_t, 1>(a, s);
   if (p->Cin == 1024) return bf ? launch_pws<uint16_t, 2>(a, s) : launch_pws<f16_t, 2>(a, s);
   return bf ? launch_pws<uint16_t, 4>(a, s) : launch_pws<f16_t, 4>(a, s);

@@ -279,7 +279,7 @@ class Engine:
             if cls in ("conv3x3_rows_kernel", "conv3x3_rows2_kernel"):          # ... per input channel count for the row-streaming kernels
                 cls = "%s<%d>" % (cls, x.C)
             if cls == "conv1x1_pws_kernel":           # ... per K length for the weight-stationary pointwise kernel
-                cls = "conv1x1_pws_kernel<%d>" % x.C
+                cls = ("conv1x1_pwq_kernel<%d>" if x.C == 256 else "conv1x1_pws_kernel<%d>") % x.C
             if cls == "conv3x3_wsr_kernel":           # ... and per (channels, ReLU) for the weight-stationary kernel
                 cls = "conv3x3_wsr_kernel<%d,%s%s>" % (x.C, "relu" if relu else "linear", ",post%d" % post_mode if post is not None else "")
             es = x.t.element_size()

@@ -179,6 +179,8 @@ PWS_CASES = [
     (2, 2048, 25, 42, 512, True, None),      # res5 conv1: four K slices, 16-pixel steps
     (1, 2048, 26, 42, 256, False, None),     # fpn_lateral5
     (3, 2048, 7, 9, 128, False, "lin"),      # two cout slices of 64, 189 pixels
+    (2, 256, 50, 84, 1024, True, "lin"),     # res4 conv3 + residual: the 64-couts-per-wave form (conv1x1_pwq_kernel), 2 cout slices of 512
+    (3, 256, 13, 21, 512, False, None),      # one slice, ragged last step
 ]
 
 

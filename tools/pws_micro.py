@@ -19,6 +19,7 @@ LAYERS = [  # name, N, H, W, Cin, Cout, relu, residual mode
     ("res5 conv3", B, 25, 42, 512, 2048, True, "lin"),
     ("fpn_lateral5", B, 25, 42, 2048, 256, False, None),
     ("fpn_lateral3", B, 100, 168, 512, 256, False, "up"),
+    ("res4 conv3", B, 50, 84, 256, 1024, True, "lin"),
 ]
 only = os.environ.get("LAYERS")
 g = torch.Generator().manual_seed(1)
