@@ -469,7 +469,7 @@ def main():
     # which part is far from either roof
     hbm = {}
     for c, v in agg.items():
-        if c.startswith(("conv1x1_stream_kernel", "bottleneck_tail64_kernel", "stem_pool_kernel", "conv1x1_pws_kernel", "conv1x1_pwq_kernel")) and v[1] > 0:
+        if c.startswith(("conv1x1_stream_kernel", "bottleneck_tail64_kernel", "bottleneck_pair128_kernel", "stem_pool_kernel", "conv1x1_pws_kernel", "conv1x1_pwq_kernel")) and v[1] > 0:
             hbm[c] = {"bound": "hbm", "achieved": round(v[3] / v[1] / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(v[3] / v[1] / PEAK_HBM, 4),
                       "alg_mb_per_step": round(v[3] / args.steps / 1e6, 1), "ms_per_step": round(1e3 * v[1] / args.steps, 3), "calls_per_step": v[2] // args.steps,
                       "tflops": round(v[0] / v[1] / 1e12, 1)}

@@ -92,6 +92,7 @@ class Engine:
         self.fuse_bottleneck = True   # res2 blocks: conv2 -> conv3 -> next conv1 in one launch (bottleneck_tail)
         self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
         self.fuse_shortcut = _os.environ.get("DP_FUSE_SHORTCUT", "1") != "0"   # block-0 projection shortcut as K planes of conv3 (16-bit modes)
+        self.fuse_pair = _os.environ.get("DP_FUSE_PAIR", "1") != "0"   # A/B knob: 0 = conv3 and the next block's conv1 of res3's plain blocks as two launches
         self.group_deconv = _os.environ.get("DP_GROUP_DECONV", "1") != "0"   # A/B knob: 0 = the predictor's four sub-pixel convolutions as four launches
         self.split_k_on = _os.environ.get("DP_SPLIT_K", "1") != "0"   # A/B knob: layers with PackedConv.split_k run unsplit
         self.decoder_fold = True      # 16-bit modes: the decoder's level sum in the conv epilogues (post_res) instead of a merge pass
@@ -417,6 +418,46 @@ class Engine:
         self.flops_last += flops
         return Act(out, N, H, W, l3.cout), (Act(t1n, N, H, W, l1n.cout) if l1n is not None else None)
 
+    def bottleneck_pair(self, l3, l1n, t2, residual):
+        """conv3 (+ residual, ReLU) -> conv1 of the next block in one launch (dp_bottleneck_pair_nhwc: the plain blocks of res3).
+        Returns (block output, next block's conv1 output), or None when the library has no fused kernel for the shape (fp32 parity
+        mode, other stages, tiny widths): the caller then runs the layers one by one."""
+        if not self.fuse_pair or l1n is None:
+            return None
+        p = L.PairParams()
+        N, H, W = t2.N, t2.H, t2.W
+        p.Cmid, p.Cout, p.Cmid_next, p.Kpad3, p.Kpad1n, p.dtype = l3.cin, l3.cout, l1n.cout, l3.kpad, l1n.kpad, self.dt
+        if (l3.stride != 1 or l3.ntaps != 1 or l1n.stride != 1 or l1n.ntaps != 1 or t2.C != l3.cin or residual.C != l3.cout or l1n.cin != l3.cout
+                or (residual.H, residual.W) != (H, W)):
+            return None
+        # 32-bit buffer offsets inside the kernel: large batches go image chunk by image chunk (pixels are independent)
+        per = max(1, ((1 << 31) // (l3.cout * 2) - 64) // (H * W))
+        p.M = min(N, per) * H * W
+        if not self.lib.dp_bottleneck_pair_supported(C.byref(p)):
+            return None
+        out = self._empty((N, H, W, l3.cout))
+        t1n = self._empty((N, H, W, l1n.cout))
+        p.w3, p.w1n, p.b3, p.b1n = l3.weight.data_ptr(), l1n.weight.data_ptr(), l3.bias.data_ptr(), l1n.bias.data_ptr()
+        es = out.element_size()
+        flops = 2 * (l3.macs_per_pixel + l1n.macs_per_pixel) * N * H * W
+        prof = self.prof is not None and N * H * W > 0
+        if prof:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+        for n0 in range(0, N, per):
+            n = min(per, N - n0)
+            px = n0 * H * W
+            p.M = n * H * W
+            p.t2, p.residual = t2.t.data_ptr() + px * t2.C * es, residual.t.data_ptr() + px * residual.C * es
+            p.out, p.next_t1 = out.data_ptr() + px * l3.cout * es, t1n.data_ptr() + px * l1n.cout * es
+            L.check(self.lib.dp_bottleneck_pair_nhwc(C.byref(p), self._stream()), "dp_bottleneck_pair_nhwc[%s]" % l3.name)
+        if prof:
+            e1.record(torch.cuda.current_stream(self.device))
+            nbytes = N * H * W * es * (t2.C + 2 * l3.cout + l1n.cout) + (l3.weight.numel() + l1n.weight.numel()) * es
+            self.prof.append(("bottleneck_pair128_kernel", flops, e0, e1, "%s+next conv1 %dx%dx%d->%d->%d" % (l3.name, H, W, t2.C, l3.cout, l1n.cout), nbytes))
+        self.flops_last += flops
+        return Act(out, N, H, W, l3.cout), Act(t1n, N, H, W, l1n.cout)
+
     # ------------------------------------------------------------------ stages
     def preprocess(self, images_u8, Hp, Wp, hwc=False):
         """-> the normalised, zero-padded image in the PAIRED layout the stem consumes ([n, Hp, Wp / 2 + 3, 8]: two 4-channel
@@ -491,7 +532,11 @@ class Engine:
                     x = self.conv(fused_sc, t, relu=True, in2=x)
                 else:
                     t = self.conv(Ls[p + "conv2"], t, relu=True)
-                    x = self.conv(Ls[p + "conv3"], t, relu=True, residual=shortcut)
+                    pair = self.bottleneck_pair(Ls[p + "conv3"], l1n, t, shortcut) if not sc else None
+                    if pair is not None:       # conv3 + residual + ReLU -> the next block's conv1, the block output written once
+                        x, t_next = pair
+                    else:
+                        x = self.conv(Ls[p + "conv3"], t, relu=True, residual=shortcut)
             res[stage] = x
         feats = {}
         with self._stage("backbone.fpn"):

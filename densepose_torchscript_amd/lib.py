@@ -54,6 +54,12 @@ class BottleneckParams(C.Structure):
                 ("dtype", c_i32)]
 
 
+class PairParams(C.Structure):
+    _fields_ = [("t2", c_void_p), ("residual", c_void_p), ("out", c_void_p), ("next_t1", c_void_p),
+                ("w3", c_void_p), ("w1n", c_void_p), ("b3", c_void_p), ("b1n", c_void_p),
+                ("M", c_i64), ("Cmid", c_i32), ("Cout", c_i32), ("Cmid_next", c_i32), ("Kpad3", c_i32), ("Kpad1n", c_i32), ("dtype", c_i32)]
+
+
 class StemPoolParams(C.Structure):
     _fields_ = [("in_", c_void_p), ("weight", c_void_p), ("bias", c_void_p), ("out", c_void_p),
                 ("N", c_i32), ("Hp", c_i32), ("Wp", c_i32), ("Cout", c_i32), ("Kpad", c_i32), ("dtype", c_i32)]
@@ -167,6 +173,8 @@ SYMBOLS = {
     "dp_resize_preprocess_u8_batch": (c_int, [C.POINTER(ResizeParams), C.POINTER(c_void_p), c_int, C.POINTER(PreprocessParams), c_void_p]),
     "dp_preprocess_u8_frames": (c_int, [C.POINTER(PreprocessParams), C.POINTER(c_void_p), c_int, c_void_p]),
     "dp_iuv_extract": (c_int, [C.POINTER(IuvExtractParams), c_void_p]),
+    "dp_bottleneck_pair_supported": (c_int, [C.POINTER(PairParams)]),
+    "dp_bottleneck_pair_nhwc": (c_int, [C.POINTER(PairParams), c_void_p]),
     "dp_set_policy": (c_int, [C.c_char_p, c_i64]),
     "dp_get_policy": (c_int, [C.c_char_p, C.POINTER(c_i64)]),
     "dp_reset_policy": (None, []),

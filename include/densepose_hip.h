@@ -215,6 +215,29 @@ int dp_bottleneck_tail_supported(const dp_bottleneck_params* p);
 int dp_bottleneck_tail_nhwc(const dp_bottleneck_params* p, dp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K4  resnet.py:199-205 of one BottleneckBlock + resnet.py:192-193 of the NEXT block, in ONE launch (ABI 6):
+ *       out     = relu(conv3(t2) + b3 + residual)      1x1, Cmid -> Cout
+ *       next_t1 = relu(conv1'(out) + b1')              1x1, Cout -> Cmid_next
+ * for the plain blocks of res3 (Cmid 128, Cout 512, Cmid_next 128, 16-bit storage): both weight matrices stay in the register file, the
+ * block output is written once and never read back. `out` is bit-identical to dp_conv2d_nhwc's; next_t1 adds eight 64-channel partial
+ * sums in a fixed order (its own summation order: a call site uses this entry point for every batch size or never). Pointwise layers:
+ * M = N * H * W pixels, plain NHWC tensors. Anything else: DP_ERR_UNSUPPORTED (dp_bottleneck_pair_supported() == 0), the caller runs
+ * the two layers one by one.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* t2;        /* [M][Cmid] dtype: conv2 output of this block */
+  const void* residual;  /* [M][Cout] dtype: block input */
+  void* out;             /* [M][Cout] dtype */
+  void* next_t1;         /* [M][Cmid_next] dtype */
+  const void* w3; const void* w1n;      /* packed weights ([Cout_w][Kpad], see dp_conv_params) */
+  const float* b3; const float* b1n;
+  int64_t M;
+  int32_t Cmid, Cout, Cmid_next, Kpad3, Kpad1n, dtype;
+} dp_pair_params;
+int dp_bottleneck_pair_supported(const dp_pair_params* p);
+int dp_bottleneck_pair_nhwc(const dp_pair_params* p, dp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K3  resnet.py:350-354  BasicStem.forward in ONE launch: 7x7 stride-2 pad-3 conv + FrozenBN + ReLU + F.max_pool2d(3, 2, 1).
  * in: the paired-pixel image of dp_preprocess_u8 (paired = 1); weight / bias: the stem packed over that layout (K = 7 kernel
  * rows x 4 cells x 8 = 224, Kpad 256: pack.stem_paired_conv / dp_pack_conv_weights with taps (dy, dxp)). The conv output is

@@ -68,7 +68,7 @@ def test_struct_layout_matches_c(built, tmp_path):
              "dp_roi_align_params": built.RoiAlignParams, "dp_box_decode_params": built.BoxDecodeParams,
              "dp_postprocess_params": built.PostprocessParams, "dp_iuv_params": built.IuvParams,
              "dp_groupnorm_params": built.GroupNormParams, "dp_resize_params": built.ResizeParams,
-             "dp_iuv_extract_params": built.IuvExtractParams}
+             "dp_iuv_extract_params": built.IuvExtractParams, "dp_pair_params": built.PairParams}
     src = '#include <stdio.h>\n#include "densepose_hip.h"\nint main(){' + "".join(
         'printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in names) + "return 0;}"
     c = tmp_path / "s.c"

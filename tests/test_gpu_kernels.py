@@ -352,6 +352,58 @@ def test_bottleneck_tail_equals_layer_by_layer(eng, dt, case):
     assert bool(((got - y3).abs() <= 2 * ulp * y3.abs() + 2e-2).all()), float((got - y3).abs().max())
 
 
+PAIR_CASES = [
+    # N, H, W of a res3-shaped pair (128 -> 512 -> 128)
+    (2, 100, 168),      # two frames at the headline geometry: 33600 pixels = 2100 steps over 256 workgroups (8 - 9 steps each)
+    (3, 13, 21),        # 819 pixels: fewer steps than workgroups, ragged last step
+    (1, 1, 1),          # a single pixel
+    (2, 37, 45),        # odd sizes, a few steps per workgroup
+]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_bottleneck_pair_res3(eng, dt, case):
+    """dp_bottleneck_pair_nhwc: conv3 + residual + ReLU of a res3 block and conv1 + ReLU of the next one (resnet.py:199-205, :192-193)
+    in one launch. The block output is BIT-identical to the separate conv3 launch; the next block's conv1 output equals the separate
+    launch up to its summation order (eight 64-channel partial sums instead of one chain) and torch in fp64; every image alone equals the
+    image inside the batch bit for bit."""
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    e = eng[dt]
+    N, H, W = case
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W)
+    mk = lambda co, ci: torch.randn((co, ci, 1, 1), generator=g) * (1.0 / ci) ** 0.5  # noqa: E731
+    w3, w1 = _round(mk(512, 128), dt), _round(mk(128, 512), dt)
+    b3, b1 = torch.randn((512,), generator=g) * 0.5, torch.randn((128,), generator=g) * 0.5
+    l3 = conv_from_oihw("conv3", w3.numpy(), b3.numpy(), 128, 1, 0, 1, e.dt, e.device)
+    l1 = conv_from_oihw("conv1n", w1.numpy(), b1.numpy(), 512, 1, 0, 1, e.dt, e.device)
+    t2 = _round(F.relu(torch.randn((N, 128, H, W), generator=g)), dt)
+    res = _round(torch.randn((N, 512, H, W), generator=g), dt)
+    ta = Act(_nhwc(t2, 128, e.tdt, e.device), N, H, W, 128)
+    ra = Act(_nhwc(res, 512, e.tdt, e.device), N, H, W, 512)
+    x_ref = e.conv(l3, ta, relu=True, residual=ra)
+    n_ref = e.conv(l1, x_ref, relu=True)
+    fused = e.bottleneck_pair(l3, l1, ta, ra)
+    assert fused is not None, "the library must have a fused kernel for the res3 shape"
+    x_f, n_f = fused
+    torch.cuda.synchronize()
+    assert torch.equal(x_f.t, x_ref.t)
+    ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    d = (n_f.t.float() - n_ref.t.float()).abs()
+    assert bool((d <= 2 * ulp * n_ref.t.float().abs() + 1e-3).all()), float(d.max())
+    y3 = _round(F.relu(F.conv2d(t2.double(), w3.double(), b3.double()) + res.double()).float(), dt).double()
+    y1 = F.relu(F.conv2d(y3, w1.double(), b1.double()))
+    got = n_f.t.float().cpu().permute(0, 3, 1, 2).double()
+    assert bool(((got - y1).abs() <= ulp * y1.abs() + 2e-3).all()), float((got - y1).abs().max())
+    for i in sorted({0, N - 1}):
+        one = e.bottleneck_pair(l3, l1, Act(ta.t[i:i + 1].contiguous(), 1, H, W, 128), Act(ra.t[i:i + 1].contiguous(), 1, H, W, 512))
+        torch.cuda.synchronize()
+        assert torch.equal(one[0].t[0], x_f.t[i]) and torch.equal(one[1].t[0], n_f.t[i]), i
+    # other widths and the fp32 parity mode have no fused kernel: the helper says so
+    assert eng["fp32"].bottleneck_pair(l3, l1, ta, ra) is None
+
+
 def test_bottleneck_tail_unsupported_shapes_fall_back(eng):
     """fp32 parity mode and non-res2 widths have no fused kernel: the engine helper says so instead of launching."""
     from densepose_torchscript_amd.engine import Act
