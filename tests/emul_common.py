@@ -126,7 +126,17 @@ def run_forced(name, dtype, engine_opts=None):
         key = next(k for k, v in eng.model.gn.items() if v is gn)
         side = int(round(HW ** 0.5))
         rec.setdefault("gn:" + key, []).append(x_t.float().cpu().reshape(R, HW, c_stride)[:, :, c_off: c_off + Cc].permute(0, 2, 1).reshape(R, Cc, side, side))
-    eng.conv, eng.groupnorm = conv, groupnorm
+    pair0 = eng.bottleneck_pair
+
+    def pair(l3, l1n, t2, residual):
+        # conv3 + residual -> the next block's conv1 in one launch (dp_bottleneck_pair_nhwc): both outputs are layer outputs like any other
+        # (conv3's is bit-identical to the separate launch, conv1' has its own summation order: exactly what this test is for)
+        res = pair0(l3, l1n, t2, residual)
+        if res is not None:
+            for layer, act in ((l3, res[0]), (l1n, res[1])):
+                rec.setdefault(layer.name, []).append(act.t.float().cpu().permute(0, 3, 1, 2)[:, : layer.cout])
+        return res
+    eng.conv, eng.groupnorm, eng.bottleneck_pair = conv, groupnorm, pair
     out = {k: v.cpu() for k, v in pred(torch.from_numpy(img)).items()}
     torch.cuda.synchronize()
     fused = [p for p in ("backbone.bottom_up.%s.%d." % (st, b) for st, b, *_ in resnet_blocks(cfg))
