@@ -1146,6 +1146,8 @@ bool rows_common_ok(const dp_conv_params* p, int g) {
          !p->residual && !p->out_f32 && !p->head_out && !p->in2 && !p->post_res && p->post_mode == 0 && p->split_k <= 1 && p->out &&
          p->osW >= p->Cout && p->osW % 8 == 0 && p->osH == (long long)p->W * p->osW && p->osN == (long long)p->H * p->W * p->osW &&
          p->Cout <= p->Cout_w && p->Cout_w % 64 == 0 &&
+         // 16-byte LDS-DMA loads and buffer stores relative to these bases: an unaligned caller falls through to the tiled kernels
+         (((uintptr_t)p->in | (uintptr_t)p->out | (uintptr_t)p->weight) & 15) == 0 &&
          (long long)(2 * g) * p->H * p->W * p->Cin * 2 < (1ll << 30) && (long long)(2 * g) * p->H * p->W * p->osW * 2 < (1ll << 30);
 }
 

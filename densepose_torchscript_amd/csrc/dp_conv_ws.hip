@@ -534,6 +534,7 @@ bool dp_conv_wsr_ok(const dp_conv_params* p) {
          (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == -1 && p->wi_off == -1 && p->H == p->Ho && p->W == p->Wo &&
          !p->residual && !p->out_f32 && !p->head_out && p->out && p->osW == p->Cout && p->osH == (long long)p->W * p->Cout &&
          p->osN == (long long)p->H * p->W * p->Cout && p->H >= 2 * rp && M >= min_m && M * 2 * p->Cin < (1ll << 31) &&
+         (((uintptr_t)p->in | (uintptr_t)p->out | (uintptr_t)p->weight | (uintptr_t)p->post_res) & 15) == 0 &&
          (p->post_res == nullptr ? p->post_mode == 0
                                  : (p->Cin == 256 && p->relu && (p->post_mode == 1 || (p->post_mode == 2 && p->H % 2 == 0 && p->W % 2 == 0))));
 }

@@ -351,7 +351,7 @@ class Engine:
         p.Cout_w, p.Kpad, p.stride, p.ntaps, p.dtype = layer.cout_w, layer.kpad, layer.stride, layer.ntaps, self.dt
         p.hi_off, p.wi_off, p.out_f32 = layer.hi_off, layer.wi_off, 1
         p.osN, p.osH, p.osW = 1, 1, layer.cout          # (a pixel-shuffle output: not a plain NHWC tensor)
-        p.out = 1
+        p.out = 4096
         if n_dev is not None:
             p.n_dev = n_dev.data_ptr()
         return layer.stride == 1 and self.lib.dp_conv2d_kernel_class(C.byref(p)) in (3, 4)
@@ -366,8 +366,8 @@ class Engine:
         p.Cout_w, p.Kpad, p.stride, p.ntaps, p.dtype, p.relu = layer.cout_w, layer.kpad, 1, layer.ntaps, self.dt, 1
         p.hi_off, p.wi_off = layer.hi_off, layer.wi_off
         p.osN, p.osH, p.osW = x.H * x.W * layer.cout, x.W * layer.cout, layer.cout
-        p.out = 1                      # placeholders: only NULL / non-NULL matters to the class query
-        p.post_res, p.post_mode = 1, post_mode
+        p.out = 4096                      # placeholders: only NULL / non-NULL matters to the class query
+        p.post_res, p.post_mode = 4096, post_mode
         p.shared_chip = int(self._shared_chip)
         return self.lib.dp_conv2d_kernel_class(C.byref(p)) == 6
 

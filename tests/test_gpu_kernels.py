@@ -112,6 +112,7 @@ STREAM_CASES = [
     (1, 256, 65, 64, 256, 1, 1, 0, 1, False, False),   # decoder predictor
     (1, 256, 66, 63, 1024, 1, 1, 0, 1, True, True),    # res4 conv3: four cout slices
     (2, 512, 50, 47, 128, 1, 1, 0, 1, True, False),    # res3 conv1: 128 couts, K = 16 planes (the NB = 2 instance)
+    (2, 64, 50, 47, 64, 1, 1, 0, 1, True, False),      # res2.0 conv1: the 64-cout instance (Cout 64 / Cout_w 128), ragged M
 ]
 
 
@@ -163,9 +164,73 @@ def test_conv2d_stream_kernel(eng, dt, case, policy):
     p = L.ConvParams()
     N, Cin, H, W, Cout = case[:5]
     p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, Cin, H, W, Cout, Cout, Cin
+    p.Cout_w = max(Cout, 128)
     p.stride, p.ntaps, p.dtype, p.out_f32 = 1, 1, eng[dt].dt, 0
     p.osN, p.osH, p.osW = H * W * Cout, W * Cout, Cout
+    if Cout == 64:      # the 64-cout instance is the policy's own choice (the conv_big override sends Cout <= 64 to the generic kernel)
+        policy.default("conv_big")
+        test_conv2d_matches_torch(eng, dt, case)      # ... and computes the same layer correctly there (fp32-out launch: generic; see below)
+        from densepose_torchscript_amd.engine import Act
+        from densepose_torchscript_amd.pack import conv_from_oihw
+        e = eng[dt]
+        g = torch.Generator().manual_seed(64)
+        x = _round(torch.randn((N, Cin, H, W), generator=g), dt)
+        w = _round(torch.randn((Cout, Cin, 1, 1), generator=g) * (1.0 / Cin) ** 0.5, dt)
+        layer = conv_from_oihw("c64", w.numpy(), np.zeros(Cout, np.float32), Cin, 1, 0, 1, e.dt, e.device)
+        xa = Act(_nhwc(x, Cin, e.tdt, e.device), N, H, W, Cin)
+        got = e.conv(layer, xa, relu=True)                   # storage-type output: the streaming instance
+        policy.set("conv_stream", 0)
+        want = e.conv(layer, xa, relu=True)                  # the generic K64 kernel: same K order, same bits
+        policy.default("conv_stream")
+        torch.cuda.synchronize()
+        assert torch.equal(got.t, want.t)
     assert orig(C.byref(p)) == 5
+    # a launch sized on the device (n_dev) never goes to the persistent kernels that ignore the count (classes 5 / 6)
+    p.n_dev = 4096
+    assert orig(C.byref(p)) in (0, 1, 2, 3, 4)
+
+
+def test_split_k_is_a_hint_and_n_dev_launches_skip_dead_images(eng):
+    """dp_conv_params.split_k on a layer the split instances do not take (a residual here) runs UNSPLIT, same bits, no error; and an n_dev
+    launch of a 256 -> 256 3x3 (the weight-stationary kernel's shape) runs on a tiled kernel and leaves the slots behind the live count alone."""
+    from densepose_torchscript_amd import lib as L
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw, set_split_k
+    e = eng["bf16"]
+    g = torch.Generator().manual_seed(31)
+    N, Ci, H, W, Co = 4, 256, 24, 32, 256
+    x = Act(torch.randn((N, H, W, Ci), generator=g).to(e.tdt).to(e.device), N, H, W, Ci)
+    r = Act(torch.randn((N, H, W, Co), generator=g).to(e.tdt).to(e.device), N, H, W, Co)
+    w = (torch.randn((Co, Ci, 3, 3), generator=g) * (1.0 / (9 * Ci)) ** 0.5).numpy()
+    layer = conv_from_oihw("l", w, np.zeros(Co, np.float32), Ci, 1, 1, 1, e.dt, e.device)
+    want = e.conv(layer, x, relu=True, residual=r)
+    set_split_k(layer, 3)
+    assert layer.split_k == 3
+    got = e.conv(layer, x, relu=True, residual=r)          # residual: the engine does not even pass split_k; ask the library directly too
+    torch.cuda.synchronize()
+    assert torch.equal(got.t, want.t)
+    p = L.ConvParams()
+    p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, Ci, H, W, Co, layer.cout_w, layer.kpad
+    p.stride, p.ntaps, p.dtype, p.hi_off, p.wi_off, p.relu = 1, 9, e.dt, -1, -1, 1
+    p.osN, p.osH, p.osW = H * W * Co, W * Co, Co
+    p.rsN, p.rsH, p.rsW = H * W * Co, W * Co, Co
+    out2 = torch.empty_like(want.t)
+    ws = torch.empty((3, N * H * W, Co), dtype=torch.float32, device=e.device)
+    p.in_, p.weight, p.ktab, p.bias, p.residual, p.out = x.t.data_ptr(), layer.weight.data_ptr(), layer.ktab.data_ptr(), layer.bias.data_ptr(), r.t.data_ptr(), out2.data_ptr()
+    p.split_k, p.split_ws = 3, ws.data_ptr()
+    assert e.lib.dp_conv2d_nhwc(C.byref(p), e._stream()) == 0       # DP_OK: the hint is ignored where it is illegal
+    torch.cuda.synchronize()
+    assert torch.equal(out2, want.t)
+    layer.split_k = 0
+    n_dev = torch.tensor([2], dtype=torch.int32, device=e.device)
+    p.residual, p.split_k, p.split_ws, p.n_dev = None, 0, None, n_dev.data_ptr()
+    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) in (0, 1, 2, 3, 4)
+    out3 = torch.full((N, H, W, Co), 7.0, dtype=e.tdt, device=e.device)
+    got3 = e.conv(layer, x, relu=True, out=out3, n_dev=n_dev)
+    torch.cuda.synchronize()
+    assert bool((got3.t[3:].float() == 7.0).all())      # (the image right behind the count may share the last live tile)
+    plain = e.conv(layer, x, relu=True)
+    assert torch.equal(got3.t[:2], plain.t[:2])
 
 
 PWS_CASES = [
@@ -595,7 +660,7 @@ def test_conv3x3_weight_stationary_equals_ring_kernel(eng, dt, shape, policy):
     p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, Cc, H, W, Cc, Cc, 9 * Cc
     p.stride, p.ntaps, p.dtype, p.hi_off, p.wi_off = 1, 9, e.dt, -1, -1
     p.osN, p.osH, p.osW = H * W * Cc, W * Cc, Cc
-    p.out = 1
+    p.out = 4096
     assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 6
     p.shared_chip = 1      # the host's hint "this launch runs beside other streams": same kernel, twice as many workgroups
     assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 6
@@ -700,7 +765,7 @@ def test_conv3x3_rows_kernel(eng, dt, case, variant, policy):
     p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, Ci, H, W, Co, layer.cout_w, 9 * Ci
     p.stride, p.ntaps, p.dtype, p.hi_off, p.wi_off = 1, 9, e.dt, -1, -1
     p.osN, p.osH, p.osW = H * W * Co, W * Co, Co
-    p.out = 1
+    p.out = 4096
     assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == (8 if variant.startswith("rows2") else 7)
     n_dev = None if live is None else torch.tensor([live], dtype=torch.int32, device=e.device)
     # the default policy: a call site is on this kernel class for every batch or for none - 512-channel layers whose width suits the
@@ -1470,7 +1535,7 @@ def test_conv3x3_wsr_small_maps_equal_the_ring_kernel(eng, dt, C_, policy):
         p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = N, H, W, C_, H, W, C_, layer.cout_w, 9 * C_
         p.stride, p.ntaps, p.dtype, p.hi_off, p.wi_off, p.relu = 1, 9, e.dt, -1, -1, 1
         p.osN, p.osH, p.osW = H * W * C_, W * C_, C_
-        p.out = 1
+        p.out = 4096
         policy.default("conv_ws")
         assert (e.lib.dp_conv2d_kernel_class(C.byref(p)) == 6) == (N * H * W >= 256 and H >= (6 if C_ == 256 else 8)), (N, H, W)
         policy.set("ws_min_m", "1")
