@@ -29,6 +29,27 @@ p.N, p.H, p.W, p.Ho, p.Wo, p.Cin, p.Cout = 1, 4, 4, 4, 4, 7, 8
 assert lib.dp_conv2d_nhwc(C.byref(p), None) == -1
 assert lib.dp_conv2d_kernel_class(C.byref(p)) >= 0 and lib.dp_conv2d_tile_rows(C.byref(p)) > 0
 assert lib.dp_nms_workspace_bytes(2, 1000) > 0 and lib.dp_rpn_topk_workspace_bytes(8, 200, 336, 3) > 0
+# ABI 6: the policy table (string keys, out parameter), the pair kernel's and the grouped launch's argument validation
+v = C.c_int64(0)
+for i in range(lib.dp_policy_num_keys()):
+    key = lib.dp_policy_key(i)
+    assert lib.dp_get_policy(key, C.byref(v)) == 0 and lib.dp_set_policy(key, v.value) == 0
+assert lib.dp_policy_key(lib.dp_policy_num_keys()) is None and lib.dp_policy_key(-1) is None
+assert lib.dp_set_policy(b"no_such_key", 1) == -1 and lib.dp_set_policy(None, 1) == -1 and lib.dp_get_policy(b"conv_ws", None) == -1
+assert lib.dp_set_policy(b"x" * 4096, 1) == -1
+lib.dp_reset_policy()
+q = L.PairParams()
+assert lib.dp_bottleneck_pair_supported(C.byref(q)) == 0 and lib.dp_bottleneck_pair_nhwc(C.byref(q), None) == -2
+q.Cmid, q.Cout, q.Cmid_next, q.Kpad3, q.Kpad1n, q.dtype, q.M = 128, 512, 128, 128, 512, L.DP_BF16, 64
+assert lib.dp_bottleneck_pair_supported(C.byref(q)) == 1 and lib.dp_bottleneck_pair_nhwc(C.byref(q), None) == -1     # null pointers
+q.M = 1 << 22
+assert lib.dp_bottleneck_pair_supported(C.byref(q)) == 0                                                               # beyond 32-bit offsets
+g = L.ConvParams()
+g.N, g.H, g.W, g.Ho, g.Wo, g.Cin, g.Cout, g.Cout_w, g.Kpad, g.stride, g.ntaps, g.dtype = 2, 28, 28, 28, 28, 512, 80, 128, 2048, 1, 4, L.DP_BF16
+g.in_, g.bias, g.n_groups = 4096, 4096, 5
+assert lib.dp_conv2d_nhwc(C.byref(g), None) == -1 and b"n_groups" in lib.dp_last_error()
+g.n_groups = 4
+assert lib.dp_conv2d_nhwc(C.byref(g), None) == -1 and b"group 0" in lib.dp_last_error()                                # null per-group pointers
 # the packer into exactly-sized buffers, every dtype, shapes with ragged padding
 rng = np.random.default_rng(0)
 for dtype, wdt in ((L.DP_F32, np.float32), (L.DP_BF16, np.uint16), (L.DP_F16, np.uint16)):
