@@ -4,6 +4,12 @@
 //     out = relu(conv3_1x1(t2) + b3 + residual)           64 -> 256                 (resnet.py:199-205)
 //     t1' = relu(conv1'_1x1(out) + b1')                   256 -> 64: conv1 of the NEXT block (resnet.py:192-193), optional
 //
+// First block of the stage (round 5): the projection shortcut rides in conv3's K axis instead of a residual tensor,
+//     out = relu([W3 | Ws] [t2 ; x] + b3 + bs)            (64 + 64) -> 256          (resnet.py:199-205 with 189-190)
+// (pack.dual_source_pointwise: K planes 0, 1 = conv3, planes 2, 3 = the shortcut over the block input x) - the 256-channel
+// shortcut tensor is never written nor read back; the two extra weight planes take conv1''s place in LDS, so this form has no
+// next-conv1 stage (strip walker only).
+//
 // (/root/reference/detectron2/modeling/backbone/resnet.py:189-205, FrozenBN folded by pack.py.) Run layer by layer
 // these three are HBM-bound pointwise / short-K launches that move 275 MB tensors five times per block; chained they
 // move them twice (residual in, block output out) plus the 64-channel t1 / t1' side tensors.
@@ -53,7 +59,7 @@ struct TailArgs {
   int N, H, W, M;
   int kpad2, kpad3, kpad1n;
   int hi_off, wi_off;
-  unsigned t1_bytes, out_bytes, t1n_bytes;
+  unsigned t1_bytes, out_bytes, t1n_bytes, res_bytes;
 };
 
 constexpr int kTailW2 = 18 * 64 * 64;                  // conv2: 18 K planes x 64 couts x 64 B
@@ -65,10 +71,11 @@ constexpr int kTailLds = kTailW2 + kTailW3 + kTailW1 + kTailBias;
 // One K step of the chain = 4 weight fragments (64 couts x 32 K) against the pixel fragments of the wave tile. The steps
 // of a tile are numbered 0..33: 0..17 conv2 (K plane s = tap s >> 1, channel block s & 1), 18..25 conv3 (64-cout block b, plane s), 26..33 conv1' (plane q);
 // the weight fragments of step k+1 are read from LDS into the other register set while the MFMAs of step k run.
-template <int K>
+// (C3 = K planes of conv3: 2, or 4 with the projection shortcut behind it - steps 18..33 are then conv3 + shortcut, no conv1')
+template <int K, int C3 = 2>
 __device__ __forceinline__ const unsigned char* tail_wfrag_addr(const unsigned char* w2_s, const unsigned char* w3_s, const unsigned char* w1_s) {
   if constexpr (K < 18) return w2_s + K * 4096;
-  else if constexpr (K < 26) return w3_s + ((K - 18) & 1) * 16384 + ((K - 18) >> 1) * 4096;
+  else if constexpr (K < 18 + 4 * C3) return w3_s + ((K - 18) % C3) * 16384 + ((K - 18) / C3) * 4096;
   else return w1_s + (K - 26) * 4096;
 }
 
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bottleneck_tail64_kernel(cons
   const int dstep = step_px % HW, dh = dstep / p.W, dw = dstep - dh * p.W;
 
   const __amdgpu_buffer_rsrc_t rs_t1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.t1), 0, p.t1_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.res_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_t1n = __builtin_amdgcn_make_buffer_rsrc(HAS_NEXT ? p.t1n : p.out, 0, HAS_NEXT ? p.t1n_bytes : 0u, 0x00020000);
 
@@ -350,11 +357,15 @@ struct StripArgs {
   int n_strips, n_seg, seg_rows, n_jobs;
 };
 
-template <typename T, bool HAS_NEXT>
+template <typename T, bool HAS_NEXT, bool HAS_SC>
 __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripArgs sa) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
+  static_assert(!(HAS_NEXT && HAS_SC), "the shortcut's weight planes live where conv1''s would");
   constexpr int NW = 8;
-  constexpr int NSTEP = HAS_NEXT ? 34 : 26;
+  constexpr int C3 = HAS_SC ? 4 : 2;             // K planes behind conv3's accumulators: t2 (2), then the block input (2)
+  constexpr int K3END = 18 + 4 * C3;
+  constexpr int NSTEP = HAS_NEXT ? 34 : K3END;
+  constexpr int RB = HAS_SC ? 1 : 4;             // 128-byte line groups per pixel of the residual / shortcut-input row
   const TailArgs& p = sa.t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const w2_s = smem;
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
                                        DP_LDS_PTR(w2_s + pl * 4096 + rg * 1024), 16, 0, 0);
     }
     const unsigned char* __restrict__ w3 = reinterpret_cast<const unsigned char*>(p.w3) + dp_wtile_off(srow, 0, scc, p.kpad3 * 2 / 64);   // tiled weight matrix
-    for (int piece = wave; piece < 2 * 16; piece += NW) {
+    for (int piece = wave; piece < C3 * 16; piece += NW) {     // (4 planes: the last two land in conv1''s 32 KiB)
       const int pl = piece >> 4, rg = piece & 15;
       __builtin_amdgcn_global_load_lds(DP_GLOBAL_PTR(w3 + ((long long)rg * (p.kpad3 * 2 / 64) + pl) * 1024),
                                        DP_LDS_PTR(w3_s + pl * 16384 + rg * 1024), 16, 0, 0);
@@ -404,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
   // the three column taps of conv2 (pack.py enumerates the 3 x 3 taps row-major; tap-major K): this kernel needs the plain
   // 3 x 3, pad 1 geometry - column displacement -1, 0, +1 and row displacement -1, 0, +1 (checked on the host)
   const __amdgpu_buffer_rsrc_t rs_t1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.t1), 0, p.t1_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.res_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_t1n = __builtin_amdgcn_make_buffer_rsrc(HAS_NEXT ? p.t1n : p.out, 0, HAS_NEXT ? p.t1n_bytes : 0u, 0x00020000);
   constexpr int OOB = (int)0x80000000;
@@ -451,16 +462,16 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
     };
     auto res_load = [&](int rr, int b, int k) __attribute__((always_inline)) -> u32x4 {
       const bool ok = rr < r1 && px_col[k] >= 0;
-      return __builtin_amdgcn_raw_buffer_load_b128(rs_res, ok ? ((img + rr) * p.W + px_col[k]) * 512 + b * 128 + ci * 16 : OOB, 0, 0);
+      return __builtin_amdgcn_raw_buffer_load_b128(rs_res, ok ? ((img + rr) * p.W + px_col[k]) * (RB * 128) + b * 128 + ci * 16 : OOB, 0, 0);
     };
 
     u32x4 row[4][3];     // t1 rows r-1, r, r+1 (natural layout) and the row being prefetched
-    u32x4 rres[4][2];    // residual of row r: 64-cout block b, pixel octet k (whole 128-byte lines)
+    u32x4 rres[RB][2];   // residual of row r: 64-cout block b, pixel octet k (whole 128-byte lines); HAS_SC: the block input's 64 channels
     load_row(r0 - 1, row[0]);
     load_row(r0, row[1]);
     load_row(r0 + 1, row[2]);
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < RB; ++b)
 #pragma unroll
       for (int k = 0; k < 2; ++k) rres[b][k] = res_load(r0, b, k);
 
@@ -472,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
       u32x4 bfr[3][2];      // B fragments of the kernel row being multiplied: [dx][channel block]
       u32x4 tf[2];          // t2 (conv3's B fragments)
       u32x4 xf[8];          // block output (conv1''s B fragments)
-      u32x4 rfr[4][2];      // residual runs of the four 64-cout blocks (fragment shape)
+      u32x4 rfr[RB][2];     // residual runs of the four 64-cout blocks (fragment shape); HAS_SC: the block input's two K planes
       f32x4 acc[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) wfr[0][i] = *reinterpret_cast<const u32x4*>(w2_s + i * 1024 + rd);
@@ -504,11 +515,11 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
         constexpr int K = decltype(kk)::value;
         u32x4 (&wf)[4] = wfr[K % 3];
         if constexpr (K + 2 < NSTEP) {   // weight fragments of step K + 2 fly while the MFMAs of steps K and K + 1 run
-          const unsigned char* nx = tail_wfrag_addr<K + 2>(w2_s, w3_s, w1_s) + rd;
+          const unsigned char* nx = tail_wfrag_addr<K + 2, C3>(w2_s, w3_s, w1_s) + rd;
 #pragma unroll
           for (int i = 0; i < 4; ++i) wfr[(K + 2) % 3][i] = *reinterpret_cast<const u32x4*>(nx + i * 1024);
         }
-        if constexpr (K == 0 || (K >= 18 && ((K - 18) & 1) == 0 && K < 26) || K == 26) {
+        if constexpr (K == 0 || (K >= 18 && K < K3END && (K - 18) % C3 == 0) || K == K3END) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -517,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
           constexpr int dy = K / 6, dx = (K % 6) >> 1, cb = K & 1;
 #pragma unroll
           for (int i = 0; i < 4; ++i) Mma<T>::run(wf[i], bfr[dx][cb], acc[i]);
-          if constexpr (K >= 1 && K <= 4) {
+          if constexpr (K >= 1 && K <= RB) {
             // residual of 64-cout block K - 1 (the buffer is idle between two kernel rows): whole lines -> LDS -> the two
             // runs this lane adds in conv3's epilogue; the line registers are refilled with the next row's residual
             constexpr int b = K - 1;
@@ -546,13 +557,13 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
               for (int k = 0; k < 4; ++k) tf[h][k] = Elem<T>::pack2(v[2 * k], v[2 * k + 1]);
             }
           }
-        } else if constexpr (K < 26) {
-          // ---- conv3, 64-cout block b, K plane sp
-          constexpr int b = (K - 18) >> 1, sp = (K - 18) & 1;
+        } else if constexpr (K < K3END) {
+          // ---- conv3, 64-cout block b, K plane sp (planes 2, 3: the projection shortcut over the block input)
+          constexpr int b = (K - 18) / C3, sp = (K - 18) % C3;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) Mma<T>::run(wf[i], tf[sp], acc[i]);
+          for (int i = 0; i < 4; ++i) Mma<T>::run(wf[i], sp < 2 ? tf[sp & 1] : rfr[0][sp & 1], acc[i]);
           if constexpr (sp == 0 && b > 0) flush_out(b - 1);      // the previous block's lines, one step after they were written
-          if constexpr (sp == 1) {
+          if constexpr (sp == C3 - 1) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               constexpr int qb = 2 * b;
@@ -565,11 +576,13 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
                 v[k] = acc[2 * h][k] + b0[k];
                 v[4 + k] = acc[2 * h + 1][k] + b1[k];
               }
-              const u32x4 rv = rfr[b][h];
+              if constexpr (!HAS_SC) {
+                const u32x4 rv = rfr[b][h];
 #pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                v[2 * k] += Elem<T>::unpack(rv[k] & 0xffffu);
-                v[2 * k + 1] += Elem<T>::unpack(rv[k] >> 16);
+                for (int k = 0; k < 4; ++k) {
+                  v[2 * k] += Elem<T>::unpack(rv[k] & 0xffffu);
+                  v[2 * k + 1] += Elem<T>::unpack(rv[k] >> 16);
+                }
               }
               u32x4 pk;
 #pragma unroll
@@ -644,12 +657,12 @@ int launch_tail(const TailArgs& a, hipStream_t stream) {
   return dp_check_launch("bottleneck_tail64_kernel");
 }
 
-template <typename T, bool HAS_NEXT>
+template <typename T, bool HAS_NEXT, bool HAS_SC = false>
 int launch_strip(const TailArgs& a, hipStream_t stream) {
   static bool attr_set = false;
   static int cus = 0;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_strip64_kernel<T, HAS_NEXT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bottleneck_strip64_kernel<T, HAS_NEXT, HAS_SC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, kStripLds);
     cus = tail_num_cus();
     attr_set = true;
@@ -670,7 +683,7 @@ int launch_strip(const TailArgs& a, hipStream_t stream) {
   sa.n_jobs = (int)jobs;
   int gx = (int)((jobs + 7) / 8);
   if (gx > cus) gx = cus;
-  hipLaunchKernelGGL((bottleneck_strip64_kernel<T, HAS_NEXT>), dim3(gx), dim3(512), kStripLds, stream, sa);
+  hipLaunchKernelGGL((bottleneck_strip64_kernel<T, HAS_NEXT, HAS_SC>), dim3(gx), dim3(512), kStripLds, stream, sa);
   return dp_check_launch("bottleneck_strip64_kernel");
 }
 
@@ -681,8 +694,15 @@ int launch_strip(const TailArgs& a, hipStream_t stream) {
 static const char* tail_unsupported(const dp_bottleneck_params* p) {
   if (p->dtype != DP_BF16 && p->dtype != DP_F16) return "16-bit storage only";
   if (p->Cmid != 64 || p->Cout != 256) return "only the 64 -> 64 -> 256 (res2) shape is fused";
-  if (p->ntaps2 != 9 || p->Kpad2 != 576 || p->Kpad3 != 64) return "conv2 must be 3x3 over 64 channels (Kpad 576), conv3 1x1 (Kpad 64)";
+  if (p->ntaps2 != 9 || p->Kpad2 != 576) return "conv2 must be 3x3 over 64 channels (Kpad 576)";
   if (p->k_order2 != 1) return "conv2 must be packed tap-major (K = tap * 64 + channel)";
+  if (p->sc_in) {    // first block of the stage: the projection shortcut as K planes 2, 3 of conv3 (strip walker only)
+    if (p->Csc != 64 || p->Kpad3 != 128) return "shortcut form: conv3 must be the dual-source matrix over 64 + 64 channels (Kpad 128)";
+    if (p->residual || p->next_t1) return "shortcut form: no residual tensor and no next-conv1 stage (its weights' LDS holds the shortcut planes)";
+    if (p->hi_off2 != -1 || p->wi_off2 != -1) return "shortcut form: conv2 must be the plain 3x3, pad 1";
+  } else if (p->Kpad3 != 64) {
+    return "conv3 must be 1x1 over 64 channels (Kpad 64)";
+  }
   if (p->next_t1 && (p->Cmid_next != 64 || p->Kpad1n != 256)) return "next conv1 must be 256 -> 64 (Kpad 256)";
   const long long M = (long long)p->N * p->H * p->W;
   // 32-bit buffer offsets; pixels up to one grid stride of tiles past the end are addressed before the range check drops them
@@ -702,17 +722,22 @@ extern "C" int dp_bottleneck_tail_nhwc(const dp_bottleneck_params* p, dp_stream_
   if (why) return dp_fail(DP_ERR_UNSUPPORTED, "dp_bottleneck_tail_nhwc: %s", why);
   const long long M = (long long)p->N * p->H * p->W;
   if (M == 0) return DP_OK;
-  DP_REQUIRE(p->t1 && p->residual && p->out && p->w2 && p->w3 && p->ktab2 && p->b2 && p->b3, "dp_bottleneck_tail_nhwc: null pointer");
+  DP_REQUIRE(p->t1 && (p->residual || p->sc_in) && p->out && p->w2 && p->w3 && p->ktab2 && p->b2 && p->b3, "dp_bottleneck_tail_nhwc: null pointer");
   DP_REQUIRE(!p->next_t1 || (p->w1n && p->b1n), "dp_bottleneck_tail_nhwc: next_t1 given without its weights");
   TailArgs a;
-  a.t1 = p->t1; a.res = p->residual; a.out = p->out; a.t1n = p->next_t1;
+  a.t1 = p->t1; a.res = p->sc_in ? p->sc_in : p->residual; a.out = p->out; a.t1n = p->next_t1;
   a.w2 = p->w2; a.w3 = p->w3; a.w1n = p->w1n; a.ktab2 = reinterpret_cast<const i32x4*>(p->ktab2);
   a.b2 = p->b2; a.b3 = p->b3; a.b1n = p->b1n;
   a.N = p->N; a.H = p->H; a.W = p->W; a.M = (int)M;
   a.kpad2 = p->Kpad2; a.kpad3 = p->Kpad3; a.kpad1n = p->Kpad1n;
   a.hi_off = p->hi_off2; a.wi_off = p->wi_off2;
   a.t1_bytes = (unsigned)(M * 128); a.out_bytes = (unsigned)(M * 512); a.t1n_bytes = (unsigned)(M * 128);
+  a.res_bytes = p->sc_in ? (unsigned)(M * 128) : a.out_bytes;
   hipStream_t s = as_stream(stream);
+  if (p->sc_in) {
+    DP_REQUIRE((long long)p->N * ((p->W + 15) / 16) * p->H < (1ll << 30), "dp_bottleneck_tail_nhwc: too many strip jobs");
+    return p->dtype == DP_BF16 ? launch_strip<uint16_t, false, true>(a, s) : launch_strip<f16_t, false, true>(a, s);
+  }
   // two kernels for the same arithmetic: the strip walker (whole-line memory traffic, default whenever conv2 is the plain
   // 3x3 / pad 1 it is written for) and the tile kernel (any tap offsets; policy key tail_kernel = 1 selects it for A/B runs)
   const bool strip = dp_policy().tail_kernel == 0 && p->hi_off2 == -1 && p->wi_off2 == -1 && (long long)p->N * ((p->W + 15) / 16) * p->H < (1ll << 30);

@@ -92,6 +92,7 @@ class Engine:
         self.fuse_bottleneck = True   # res2 blocks: conv2 -> conv3 -> next conv1 in one launch (bottleneck_tail)
         self.overlap_decoder = True   # decoder on a side stream beside the RPN / box branch (see _phase_a)
         self.fuse_shortcut = _os.environ.get("DP_FUSE_SHORTCUT", "1") != "0"   # block-0 projection shortcut as K planes of conv3 (16-bit modes)
+        self.fuse_sc_tail = _os.environ.get("DP_FUSE_SC_TAIL", "1") != "0"     # ... of res2.0 too (stride 1: inside the fused bottleneck tail)
         self.fuse_pair = _os.environ.get("DP_FUSE_PAIR", "1") != "0"   # A/B knob: 0 = conv3 and the next block's conv1 of res3's plain blocks as two launches
         self.group_deconv = _os.environ.get("DP_GROUP_DECONV", "1") != "0"   # A/B knob: 0 = the predictor's four sub-pixel convolutions as four launches
         self.split_k_on = _os.environ.get("DP_SPLIT_K", "1") != "0"   # A/B knob: layers with PackedConv.split_k run unsplit
@@ -371,10 +372,12 @@ class Engine:
         p.shared_chip = int(self._shared_chip)
         return self.lib.dp_conv2d_kernel_class(C.byref(p)) == 6
 
-    def bottleneck_tail(self, l2, l3, l1n, t1, residual):
+    def bottleneck_tail(self, l2, l3, l1n, t1, residual, sc_in=None):
         """conv2 -> conv3 (+ residual, ReLU) -> conv1 of the next block in one launch (dp_bottleneck_tail_nhwc).
         Returns (block output, next block's conv1 output or None), or None when the library has no fused kernel for the
-        shape (fp32 parity mode, every stage but res2, tiny widths): the caller then runs the layers one by one."""
+        shape (fp32 parity mode, every stage but res2, tiny widths): the caller then runs the layers one by one.
+        sc_in: the block's input when l3 is the block's conv3 + projection shortcut as one dual-source layer (pack.dual_source_pointwise,
+        stride 1): the shortcut rides in conv3's K axis, there is no residual tensor and no next-conv1 stage."""
         p = L.BottleneckParams()
         N, H, W = t1.N, t1.H, t1.W
         p.N, p.H, p.W = N, H, W
@@ -382,7 +385,12 @@ class Engine:
         p.Kpad2, p.Kpad3, p.Kpad1n = l2.kpad, l3.kpad, (l1n.kpad if l1n is not None else 0)
         p.ntaps2, p.hi_off2, p.wi_off2, p.dtype = l2.ntaps, l2.hi_off, l2.wi_off, self.dt
         p.k_order2 = 0 if l2.plane_major else 1
-        if (l2.stride != 1 or l3.stride != 1 or l3.ntaps != 1 or t1.C != l2.cin or l2.cout != l3.cin or residual.C != l3.cout
+        if sc_in is not None:
+            if (l1n is not None or residual is not None or getattr(l3, "stride2", 0) != 1 or l3.cin1 != l2.cout or sc_in.C != l3.cin2
+                    or (sc_in.N, sc_in.H, sc_in.W) != (N, H, W) or l2.stride != 1 or l3.ntaps != 1 or t1.C != l2.cin):
+                return None
+            p.Csc, p.sc_in = sc_in.C, 4096             # placeholder: only NULL / non-NULL matters to the support query
+        elif (l2.stride != 1 or l3.stride != 1 or l3.ntaps != 1 or t1.C != l2.cin or l2.cout != l3.cin or residual.C != l3.cout
                 or (l1n is not None and (l1n.stride != 1 or l1n.ntaps != 1 or l1n.cin != l3.cout))):
             return None
         # 32-bit buffer offsets inside the kernel: large batches go image chunk by image chunk
@@ -407,16 +415,28 @@ class Engine:
             n = min(per, N - n0)
             px = n0 * H * W
             p.N = n
-            p.t1, p.residual, p.out = t1.t.data_ptr() + px * t1.C * es, residual.t.data_ptr() + px * residual.C * es, out.data_ptr() + px * l3.cout * es
+            p.t1, p.out = t1.t.data_ptr() + px * t1.C * es, out.data_ptr() + px * l3.cout * es
+            if sc_in is not None:
+                p.sc_in = sc_in.t.data_ptr() + px * sc_in.C * es
+            else:
+                p.residual = residual.t.data_ptr() + px * residual.C * es
             p.next_t1 = (t1n.data_ptr() + px * l1n.cout * es) if l1n is not None else None
             L.check(self.lib.dp_bottleneck_tail_nhwc(C.byref(p), self._stream()), "dp_bottleneck_tail_nhwc[%s]" % l2.name)
         if prof:
             e1.record(torch.cuda.current_stream(self.device))
-            nbytes = N * H * W * es * (t1.C + 2 * l3.cout + (l1n.cout if l1n is not None else 0)) + (l2.weight.numel() + l3.weight.numel()) * es
+            nbytes = N * H * W * es * (t1.C + l3.cout + (sc_in.C if sc_in is not None else l3.cout) + (l1n.cout if l1n is not None else 0)) + (
+                l2.weight.numel() + l3.weight.numel()) * es
             self.prof.append(("bottleneck_tail64_kernel", flops, e0, e1, "%s+conv3%s %dx%dx%d->%d" % (
-                l2.name, "+next conv1" if l1n is not None else "", H, W, t1.C, l3.cout), nbytes))
+                l2.name, "+shortcut" if sc_in is not None else "+next conv1" if l1n is not None else "", H, W, t1.C, l3.cout), nbytes))
         self.flops_last += flops
         return Act(out, N, H, W, l3.cout), (Act(t1n, N, H, W, l1n.cout) if l1n is not None else None)
+
+    def fused_shortcut_blocks(self):
+        """Prefixes of the bottleneck blocks whose projection shortcut rides in conv3's K axis (no rounded shortcut tensor): what the
+        storage-emulating oracle of the tests has to mirror."""
+        bu = "backbone.bottom_up."
+        return [p for p, stride, sc in (("%s%s.%d." % (bu, st, b), stride, sc) for st, b, _, _, _, stride, sc in resnet_blocks(self.cfg))
+                if sc and self.fuse_shortcut and (stride != 1 or self.fuse_sc_tail) and (p + "conv3+shortcut") in self.model.layers]
 
     def bottleneck_pair(self, l3, l1n, t2, residual):
         """conv3 (+ residual, ReLU) -> conv1 of the next block in one launch (dp_bottleneck_pair_nhwc: the plain blocks of res3).
@@ -516,14 +536,19 @@ class Engine:
         for bi, (stage, b, cin, cmid, cout, stride, sc) in enumerate(blocks):
             p = "%s%s.%d." % (bu, stage, b)
             with self._stage("backbone." + stage):
-                fused_sc = Ls.get(p + "conv3+shortcut") if (sc and self.fuse_shortcut) else None
+                fused_sc = Ls.get(p + "conv3+shortcut") if (sc and self.fuse_shortcut and (stride != 1 or self.fuse_sc_tail)) else None
                 shortcut = x if (not sc or fused_sc is not None) else self.conv(Ls[p + "shortcut"], x)
                 t = t_next if t_next is not None else self.conv(Ls[p + "conv1"], x, relu=True)
                 t_next = None
                 # conv1 of the next block of the SAME stage (stride 1, reads this block's output) rides in the fused tail
                 nxt = blocks[bi + 1] if bi + 1 < len(blocks) and blocks[bi + 1][0] == stage else None
                 l1n = Ls["%s%s.%d.conv1" % (bu, nxt[0], nxt[1])] if nxt is not None else None
-                fused = self.bottleneck_tail(Ls[p + "conv2"], Ls[p + "conv3"], l1n, t, shortcut) if (self.fuse_bottleneck and fused_sc is None) else None
+                fused = None
+                if self.fuse_bottleneck and fused_sc is None:
+                    fused = self.bottleneck_tail(Ls[p + "conv2"], Ls[p + "conv3"], l1n, t, shortcut)
+                elif self.fuse_bottleneck and stride == 1:
+                    # first block of res2: conv2 -> conv3 with the projection shortcut as two more K planes, one launch (no next-conv1 stage)
+                    fused = self.bottleneck_tail(Ls[p + "conv2"], fused_sc, None, t, None, sc_in=x)
                 if fused is not None:
                     x, t_next = fused
                 elif fused_sc is not None:
@@ -980,7 +1005,7 @@ class Engine:
             pinned.copy_(st["det_counts"], non_blocking=True)
         else:
             # everything that changes the captured launch sequence is part of the key
-            key = (shape, hwc, slot, self.overlap_decoder, self.decoder_after_rpn_heads, self.fuse_bottleneck, self.fuse_rpn_head, self.fuse_stem_pool, self.fork_levels, self.nms_reference, self.decoder_fold, self.fuse_shortcut)
+            key = (shape, hwc, slot, self.overlap_decoder, self.decoder_after_rpn_heads, self.fuse_bottleneck, self.fuse_rpn_head, self.fuse_stem_pool, self.fork_levels, self.nms_reference, self.decoder_fold, self.fuse_shortcut, self.fuse_sc_tail)
             entry = self._graphs.pop(key, None)
             if entry is None:
                 # every (stream slot / pipeline lane) of one geometry needs a graph of its own: never cap below the slots in use,

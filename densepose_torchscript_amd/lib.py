@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("DP_HIP_LIB") or os.path.join(_HERE, "libdensepose_hip
 CSRC = os.path.join(_HERE, "csrc")
 
 DP_F32, DP_BF16, DP_F16 = 0, 1, 2
-ABI_VERSION = 6   # == DP_ABI_VERSION of include/densepose_hip.h (bumped whenever a params struct or the symbol set changes)
+ABI_VERSION = 7   # == DP_ABI_VERSION of include/densepose_hip.h (bumped whenever a params struct or the symbol set changes)
 
 # user-facing dtype names -> (enum, element size)
 DTYPES = {"fp32": DP_F32, "float32": DP_F32, "bf16": DP_BF16, "bfloat16": DP_BF16, "fp16": DP_F16, "float16": DP_F16, "half": DP_F16}
@@ -51,7 +51,7 @@ class BottleneckParams(C.Structure):
                 ("Cmid", c_i32), ("Cout", c_i32), ("Cmid_next", c_i32),
                 ("Kpad2", c_i32), ("Kpad3", c_i32), ("Kpad1n", c_i32),
                 ("ntaps2", c_i32), ("hi_off2", c_i32), ("wi_off2", c_i32), ("k_order2", c_i32),
-                ("dtype", c_i32)]
+                ("dtype", c_i32), ("Csc", c_i32), ("sc_in", c_void_p)]
 
 
 class PairParams(C.Structure):

@@ -218,7 +218,8 @@ class PackedModel:
             # with four: 34 -> 37 us. Not set.)
             # first block of res3 / res4 / res5 in the 16-bit modes: the projection shortcut as extra K planes of conv3 (one launch,
             # the shortcut tensor is never written or read back; fp32 parity mode keeps the reference's two convolutions + add)
-            if sc and stage != "res2" and dtype != DP_F32 and A8(cmid) % 32 == 0 and A8(cin) % 32 == 0 and (A8(cmid) + A8(cin)) % 64 == 0:
+            # (res2.0, stride 1: the same matrix feeds the fused bottleneck tail, dp_bottleneck_params.sc_in - round 5)
+            if sc and dtype != DP_F32 and A8(cmid) % 32 == 0 and A8(cin) % 32 == 0 and (A8(cmid) + A8(cin)) % 64 == 0:
                 w3, s3 = _fold_bn(st[p + "conv3.weight"].astype(np.float32), st, p + "conv3.norm")
                 ws, ss = _fold_bn(st[p + "shortcut.weight"].astype(np.float32), st, p + "shortcut.norm")
                 L[p + "conv3+shortcut"] = dual_source_pointwise(p + "conv3+shortcut", w3, s3, A8(cmid), ws, ss, A8(cin), stride, dtype, device)

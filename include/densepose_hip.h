@@ -37,7 +37,7 @@ enum dp_status {
   DP_ERR_LAUNCH = -3        /* hipGetLastError() after launch */
 };
 
-#define DP_ABI_VERSION 6
+#define DP_ABI_VERSION 7
 int dp_abi_version(void);
 /* human-readable reason of the last non-zero return on this thread */
 const char* dp_last_error(void);
@@ -190,6 +190,10 @@ int dp_conv2d_tile_rows(const dp_conv_params* p);
  *       out = relu(conv3(t2) + b3 + residual)      1x1, Cmid -> Cout         (resnet.py:199-205)
  *       next_t1 = relu(conv1'(out) + b1')          1x1, Cout -> Cmid_next: conv1 of the NEXT block
  *                                                  (resnet.py:192-193), optional (next_t1 == NULL: skipped)
+ *     First block of a stage (resnet.py:189-190, the projection shortcut), sc_in != NULL:
+ *       out = relu([W3 | Ws][t2 ; sc_in] + b3 + bs)  w3 = the dual-source matrix over Cmid + Csc channels (Kpad3 = their sum),
+ *                                                  b3 = the summed shifts; residual and next_t1 must be NULL. Same bits as
+ *                                                  dp_conv2d_nhwc on conv2, then on that matrix with in2 = sc_in.
  * Weights, tap table and biases are the packed operands dp_conv2d_nhwc takes for the same layers
  * (FrozenBN folded, batch_norm.py:54-62); results are bit-identical to three dp_conv2d_nhwc calls.
  * Fused shapes: dp_bottleneck_tail_supported() (16-bit storage, Cmid 64, Cout 256 = the res2 blocks);
@@ -210,6 +214,9 @@ typedef struct {
   int32_t k_order2;      /* K order of conv2's packed weights: 0 = channel-block major (64-byte planes outer, taps inner),
                             1 = tap major (K = tap * Cmid + channel); the fused kernel takes 1 */
   int32_t dtype;
+  /* ABI 7 */
+  int32_t Csc;           /* channels of sc_in (64) */
+  const void* sc_in;     /* optional [N][H][W][Csc] dtype: the block's input, second source of conv3's K axis (see above) */
 } dp_bottleneck_params;
 int dp_bottleneck_tail_supported(const dp_bottleneck_params* p);
 int dp_bottleneck_tail_nhwc(const dp_bottleneck_params* p, dp_stream_t stream);

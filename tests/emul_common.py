@@ -28,8 +28,7 @@ def run_pair(name, dtype):
     torch.cuda.synchronize()
     out = {k: v.cpu() for k, v in out.items()}
     inter = eng.inter
-    fused = [p for p in ("backbone.bottom_up.%s.%d." % (st, b) for st, b, *_ in resnet_blocks(cfg))
-             if eng.fuse_shortcut and (p + "conv3+shortcut") in eng.model.layers]
+    fused = eng.fused_shortcut_blocks()
     fold = bool(inter.get("decoder_fold", False))
     em = StorageOracle(cfg, state, dtype, fused_shortcuts=fused, decoder_fold=fold)
     image, height, width = em.resize(torch.from_numpy(img))
@@ -139,8 +138,7 @@ def run_forced(name, dtype, engine_opts=None):
     eng.conv, eng.groupnorm, eng.bottleneck_pair = conv, groupnorm, pair
     out = {k: v.cpu() for k, v in pred(torch.from_numpy(img)).items()}
     torch.cuda.synchronize()
-    fused = [p for p in ("backbone.bottom_up.%s.%d." % (st, b) for st, b, *_ in resnet_blocks(cfg))
-             if eng.fuse_shortcut and (p + "conv3+shortcut") in eng.model.layers]
+    fused = eng.fused_shortcut_blocks()
     em = StorageOracle(cfg, state, dtype, fused_shortcuts=fused, decoder_fold=bool(eng.inter.get("decoder_fold", False)))
     det_boxes, det_scores, det_counts = eng.inter["detections"]
     R = int(det_counts[0])

@@ -417,6 +417,55 @@ def test_bottleneck_tail_equals_layer_by_layer(eng, dt, case):
     assert bool(((got - y3).abs() <= 2 * ulp * y3.abs() + 2e-2).all()), float((got - y3).abs().max())
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", [(1, 20, 24), (2, 17, 19), (3, 40, 37), (1, 1, 1), (2, 3, 70), (1, 96, 160), (2, 200, 336)])
+def test_bottleneck_tail_with_projection_shortcut(eng, dt, case):
+    """First block of res2 (resnet.py:189-205 with the projection shortcut of :189-190): conv2 -> [conv3 | shortcut] over [t2 ; block
+    input] in ONE launch (dp_bottleneck_params.sc_in) is BIT-identical to conv2 followed by the dual-source pointwise layer
+    (dp_conv_params.in2), agrees with torch in fp64, and every image alone equals the image inside the batch."""
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import dual_source_pointwise
+    e = eng[dt]
+    N, H, W = case
+    (l2, _, _), (w2, b2, w3, b3, _, _) = _tail_layers(e, N * 1000 + H * 10 + W)
+    g = torch.Generator().manual_seed(H * 1000 + W + 5)
+    ws = torch.randn((256, 64, 1, 1), generator=g) * (1.0 / 64) ** 0.5
+    bs = torch.randn((256,), generator=g) * 0.5
+    l3s = dual_source_pointwise("conv3+shortcut", w3.numpy(), b3.numpy(), 64, ws.numpy(), bs.numpy(), 64, 1, e.dt, e.device)
+    t1 = _round(F.relu(torch.randn((N, 64, H, W), generator=g)), dt)
+    x = _round(F.relu(torch.randn((N, 64, H, W), generator=g)), dt)
+    ta = Act(_nhwc(t1, 64, e.tdt, e.device), N, H, W, 64)
+    xa = Act(_nhwc(x, 64, e.tdt, e.device), N, H, W, 64)
+    t2 = e.conv(l2, ta, relu=True)
+    ref = e.conv(l3s, t2, relu=True, in2=xa)
+    fused = e.bottleneck_tail(l2, l3s, None, ta, None, sc_in=xa)
+    assert fused is not None, "the library must take the shortcut form of the res2 shape"
+    x_f, n_f = fused
+    torch.cuda.synchronize()
+    assert n_f is None and torch.equal(x_f.t, ref.t)
+    rw = lambda w: _round(w, dt).double()  # noqa: E731
+    y2 = _round(F.relu(F.conv2d(t1.double(), rw(w2), b2.double(), padding=1)).float(), dt).double()
+    y3 = F.relu(F.conv2d(y2, rw(w3), b3.double()) + F.conv2d(x.double(), rw(ws), bs.double()))
+    got = x_f.t.float().cpu().permute(0, 3, 1, 2).double()
+    ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    assert bool(((got - y3).abs() <= 2 * ulp * y3.abs() + 2e-2).all()), float((got - y3).abs().max())
+    for i in range(N if N * H * W < 20000 else 1):
+        one = e.bottleneck_tail(l2, l3s, None, Act(ta.t[i:i + 1].contiguous(), 1, H, W, 64), None, sc_in=Act(xa.t[i:i + 1].contiguous(), 1, H, W, 64))
+        torch.cuda.synchronize()
+        assert torch.equal(one[0].t[0], x_f.t[i]), i
+    # no next-conv1 stage and no residual tensor in this form; the fp32 parity mode has no fused kernel at all
+    assert e.bottleneck_tail(l2, l3s, _tail_layers(e, 1)[0][2], ta, None, sc_in=xa) is None
+    p = __import__("densepose_torchscript_amd.lib", fromlist=["x"]).BottleneckParams()
+    p.N, p.H, p.W, p.Cmid, p.Cout, p.Kpad2, p.Kpad3, p.ntaps2, p.k_order2, p.dtype = 1, 8, 8, 64, 256, 576, 128, 9, 1, e.dt
+    p.hi_off2 = p.wi_off2 = -1
+    p.Csc, p.sc_in = 64, 4096
+    assert e.lib.dp_bottleneck_tail_supported(C.byref(p)) == 1
+    p.next_t1 = 4096
+    assert e.lib.dp_bottleneck_tail_supported(C.byref(p)) == 0
+    p.next_t1, p.Kpad3 = None, 64
+    assert e.lib.dp_bottleneck_tail_supported(C.byref(p)) == 0
+
+
 PAIR_CASES = [
     # N, H, W of a res3-shaped pair (128 -> 512 -> 128)
     (2, 100, 168),      # two frames at the headline geometry: 33600 pixels = 2100 steps over 256 workgroups (8 - 9 steps each)
