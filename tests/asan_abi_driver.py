@@ -44,6 +44,16 @@ q.Cmid, q.Cout, q.Cmid_next, q.Kpad3, q.Kpad1n, q.dtype, q.M = 128, 512, 128, 12
 assert lib.dp_bottleneck_pair_supported(C.byref(q)) == 1 and lib.dp_bottleneck_pair_nhwc(C.byref(q), None) == -1     # null pointers
 q.M = 1 << 22
 assert lib.dp_bottleneck_pair_supported(C.byref(q)) == 0                                                               # beyond 32-bit offsets
+# ABI 7: the first block of res2 with its projection shortcut inside the fused tail (dp_bottleneck_params.sc_in)
+t = L.BottleneckParams()
+t.N, t.H, t.W, t.Cmid, t.Cout, t.Kpad2, t.Kpad3, t.ntaps2, t.k_order2, t.dtype = 1, 8, 8, 64, 256, 576, 128, 9, 1, L.DP_BF16
+t.hi_off2 = t.wi_off2 = -1
+t.Csc, t.sc_in = 64, 4096
+assert lib.dp_bottleneck_tail_supported(C.byref(t)) == 1 and lib.dp_bottleneck_tail_nhwc(C.byref(t), None) == -1      # null pointers
+t.residual = 4096
+assert lib.dp_bottleneck_tail_supported(C.byref(t)) == 0 and lib.dp_bottleneck_tail_nhwc(C.byref(t), None) == -2 and b"shortcut form" in lib.dp_last_error()
+t.residual, t.Csc = None, 32
+assert lib.dp_bottleneck_tail_supported(C.byref(t)) == 0
 g = L.ConvParams()
 g.N, g.H, g.W, g.Ho, g.Wo, g.Cin, g.Cout, g.Cout_w, g.Kpad, g.stride, g.ntaps, g.dtype = 2, 28, 28, 28, 28, 512, 80, 128, 2048, 1, 4, L.DP_BF16
 g.in_, g.bias, g.n_groups = 4096, 4096, 5
