@@ -11,7 +11,7 @@ ALL="dp_conv dp_conv_ws dp_conv_rows dp_conv_pw dp_bottleneck dp_pair dp_stem dp
 objs=""
 for f in $ALL; do
   if [ $f != $unit ]; then
-    [ $B/obj/$f.o -nt $f.hip ] && [ $B/obj/$f.o -nt dp_common.h ] && [ $B/obj/$f.o -nt dp_policy.h ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -c -o $B/obj/$f.o $f.hip
+    [ $B/obj/$f.o -nt $f.hip ] && [ $B/obj/$f.o -nt dp_common.h ] && [ $B/obj/$f.o -nt dp_policy.h ] && [ $B/obj/$f.o -nt ../../include/densepose_hip.h ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -c -o $B/obj/$f.o $f.hip
     objs="$objs $B/obj/$f.o"
   fi
 done
