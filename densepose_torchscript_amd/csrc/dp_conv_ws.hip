@@ -8,6 +8,9 @@
 #ifndef DP_EXP
 #define DP_EXP 0      // diagnostic builds: 1 no fragment reads, 4 no MFMAs, 8 no row fetches, 16 in-kernel phase stamps
 #endif
+#ifndef DP_WSR_LATE
+#define DP_WSR_LATE 1 // two-part form: the storing waves run their epilogue right after their matrix loop and read the hand-over first thing (0: round-4 order)
+#endif
 
 namespace {
 int ws_num_cus() {
@@ -46,11 +49,13 @@ int ws_num_cus() {
 //     staging buffer, ONE barrier per step;
 //   * waves w and w + 4 share a SIMD and the older one wins the matrix pipe whenever both are ready. Everything that is not a
 //     fragment read or an MFMA sits at the TOP of an iteration, before the wave has LDS reads in flight (an LDS-DMA issued behind
-//     outstanding ds_reads of its wave waits for them): row fetches, the hand-over read, and the PREVIOUS step's stores (the
-//     epilogue is deferred by one iteration). With two K parts the roles follow the age of the waves: older = part 1 (hand-over
-//     read + stores, then a loop of nothing but reads and MFMAs), younger = part 0 (all row fetches, MFMAs, hand-over write).
-// In-kernel phase stamps (-DDP_EXP=16) on the 200x336 level: 3456 MFMA cycles per SIMD and step out of ~5200; the rest is the
-// issue time of the row fetches (~70 cycles per 1 KiB piece up front, ~150 between the MFMAs) and the lone tail of the younger wave.
+//     outstanding ds_reads of its wave waits for them): row fetches, the hand-over read, and - with one K part - the PREVIOUS step's
+//     stores (the epilogue is deferred by one iteration). With two K parts the roles follow the age of the waves: older = part 1
+//     (hand-over read first thing, a loop of nothing but reads and MFMAs, then ITS step's epilogue and stores in the ~1800 cycles it
+//     would otherwise wait at the barrier - round 5), younger = part 0 (all row fetches, MFMAs, hand-over write).
+// In-kernel phase stamps (-DDP_EXP=16) on the 200x336 level (profiles/r5_wsr_experiments.txt): 3456 MFMA cycles per SIMD and step out of
+// ~5200. The matrix loops themselves run at 17 (older wave) and 22 (younger, mostly alone) cycles per MFMA; what is lost is the ~1000
+// cycles after the barrier in which neither wave of a SIMD multiplies yet (step bookkeeping, the younger wave's row fetches).
 // A persistent launch with a static split over exactly as many workgroups as CUs cannot rebalance when it shares the chip with
 // another stream: the host says so (dp_conv_params.shared_chip) and those launches are split over twice as many workgroups
 // (DESIGN.md section 4.1c).
@@ -176,6 +181,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
   // pad or outside the image read zeros (out-of-range buffer offset). In the steady state (RP new rows) piece j of this wave is
   // always the same (row, piece-in-row), so its per-lane part is computed once: staged pixel and byte offset inside the row.
   // With two K parts the part-0 waves issue every fetch and the part-1 waves every store.
+  // Two-part form (round 5, profiles/r5_wsr_experiments.txt): the storing wave - the older wave of its SIMD - reaches the step barrier ~1800
+  // cycles before its partner, so ITS epilogue is not deferred: bias, activation, post term and stores run right after its matrix loop, in
+  // time it would spend waiting, and its next step starts with the hand-over read instead of 430 cycles of stores.
+  constexpr bool LATE = KS > 1 && DP_WSR_LATE;
   constexpr int ND = KS == 1 ? 8 : NG;         // fetching waves
   constexpr int NJ = (RP * PPR + ND - 1) / ND; // pieces per fetching wave and step
   const bool dma_wave = h == 0;
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
     __builtin_amdgcn_raw_buffer_store_b64(pk, rs_out, ok ? e_off + t * (p.W * opix) : OOB, 0, 0);
   };
 
-  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define DP_STAMP(k) if constexpr (DP_EXP & 16) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - tl; tl = t_; }
   unsigned long long tl = (DP_EXP & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
   for (int i = 0; i < nst + KS - 1; ++i) {
@@ -339,6 +348,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
     DP_STAMP(0)
     const int sw = i - h;
     const bool had_prev = have_prev;
+    bool stored = had_prev;        // this iteration issues RP stores (behind its row fetches)
+    f32x4 acc[RP];
+    if constexpr (LATE) {          // the hand-over read goes out before any bookkeeping: its latency runs under it
+      if (h > 0 && sw >= 0 && sw < nst) {
+        const unsigned char* hb = smem + HAND + (((g * (KS - 1) + h - 1) * 2 + ((i - 1) & 1)) * RP) * 1024 + lane * 16;
+#pragma unroll
+        for (int t = 0; t < RP; ++t) acc[t] = *reinterpret_cast<const f32x4*>(hb + t * 1024);
+      }
+    }
     if (sw >= 0 && sw < nst) {
       WsrStep st = st_w[0];
       if constexpr (KS > 1) { if (h == 1) st = st_w[1]; }
@@ -349,20 +367,23 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
         if (slot >= NSLOT) slot -= NSLOT;
         va[q] = slot * ROWB + frag_lane;
       }
+      DP_STAMP(6)
 
       // Everything that is not a fragment read or an MFMA happens HERE, before the first LDS read of the iteration is in flight:
       // an LDS-DMA issued behind outstanding ds_reads of its wave waits for them (measured: ~150 cycles of wave time per piece
       // between the MFMAs against ~70 up front; 0.567 -> 0.531 ms on the 200x336 level). Order: fetches, then the hand-over
       // read, then the previous step's stores under its latency - so that at the end of the iteration "all but the last RP
       // vector-memory operations" still means "every fetch".
-      f32x4 acc[RP];
       if (fetch_inl && dma_wave) static_for<0, NJ>([&](auto jj) { issue_piece(st_i, jj); });
       asm volatile("" ::: "memory");      // the fetches stay older than the stores below
+      DP_STAMP(7)
       if constexpr (KS > 1) {
         if (h > 0) {
-          const unsigned char* hb = smem + HAND + (((g * (KS - 1) + h - 1) * 2 + ((i - 1) & 1)) * RP) * 1024 + lane * 16;
+          if constexpr (!LATE) {
+            const unsigned char* hb = smem + HAND + (((g * (KS - 1) + h - 1) * 2 + ((i - 1) & 1)) * RP) * 1024 + lane * 16;
 #pragma unroll
-          for (int t = 0; t < RP; ++t) acc[t] = *reinterpret_cast<const f32x4*>(hb + t * 1024);
+            for (int t = 0; t < RP; ++t) acc[t] = *reinterpret_cast<const f32x4*>(hb + t * 1024);
+          }
         } else {
 #pragma unroll
           for (int t = 0; t < RP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -371,7 +392,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
 #pragma unroll
         for (int t = 0; t < RP; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      DP_STAMP(8)
       if (had_prev) { epi_prepare(); static_for<0, RP>([&](auto tt) { epi_row(tt); }); }
+      DP_STAMP(9)
       if constexpr (POST != 0) {          // the storing waves fetch THIS step's post values into the registers the epilogue above
         asm volatile("" ::: "memory");    // has just consumed; they are used one iteration later (a whole MFMA phase of latency cover)
         if (KS == 1 || h == KS - 1) post_issue(st);
@@ -388,6 +411,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
       u32x4 bf[AHEAD + 1];
       static_for<0, AHEAD>([&](auto ff) { bf[decltype(ff)::value] = frag(ff); });
       __builtin_amdgcn_sched_barrier(0);
+      DP_STAMP(10)
       static_for<0, NF>([&](auto ff) {
         constexpr int f = decltype(ff)::value;
         constexpr int cbl = f / (3 * NQ), q = (f % (3 * NQ)) / 3, dx = f % 3;
@@ -414,7 +438,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
         e_col = st.c0 + fr;
         e_off = ((st.n * p.H + st.r) * p.W + e_col) * opix + (cbase + fq * 4) * 2;
         e_rows = p.H - st.r;
-        have_prev = true;
+        if constexpr (LATE) {      // this wave reaches the step barrier long before its partner: bias, activation, post term and stores now
+          epi_prepare();
+          static_for<0, RP>([&](auto tt) { epi_row(tt); });
+          stored = true;
+        } else {
+          have_prev = true;
+        }
       }
     } else {
       if (fetch_inl && dma_wave) static_for<0, NJ>([&](auto jj) { issue_piece(st_i, jj); });
@@ -428,10 +458,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
     // (the youngest vector-memory operations of a storing wave are its RP stores and, behind them, its NPL post loads)
     constexpr bool computes_post = POST != 0;
     const int npl = (computes_post && sw >= 0 && sw < nst && (KS == 1 || h == KS - 1)) ? NPL : 0;
-    if (KS == 1 && had_prev) { if (npl) wsr_wait_vm<RP + NPL>(); else wsr_wait_vm<RP>(); }
-    else if (dma_wave) wsr_wait_vm<0>();
-    else if (fetch_all) {
-      if (had_prev) { if (npl) wsr_wait_vm<RP + NPL>(); else wsr_wait_vm<RP>(); }
+    // (`stored`: RP stores were issued in this iteration - at its top from the deferred epilogue, or after the matrix loop by a storing wave of the
+    // LATE form; either way behind the fetches, and the post loads sit between the fetches and the loop)
+    if (dma_wave || fetch_all) {
+      if (stored) { if (npl) wsr_wait_vm<RP + NPL>(); else wsr_wait_vm<RP>(); }
       else { if (npl) wsr_wait_vm<NPL>(); else wsr_wait_vm<0>(); }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -446,8 +476,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wsr_kernel(const WsrArgs p) {
   if constexpr (DP_EXP & 16) {
     if (lane == 0 && p.dbg) {
 #pragma unroll
-      for (int k = 0; k < 5; ++k) p.dbg[(blockIdx.x * 8 + wave) * 8 + k] = ph[k];
-      p.dbg[(blockIdx.x * 8 + wave) * 8 + 5] = nst;
+      for (int k = 0; k < 5; ++k) p.dbg[(blockIdx.x * 8 + wave) * 16 + k] = ph[k];
+      p.dbg[(blockIdx.x * 8 + wave) * 16 + 5] = nst;
+#pragma unroll
+      for (int k = 6; k < 11; ++k) p.dbg[(blockIdx.x * 8 + wave) * 16 + k] = ph[k];
     }
   }
 #undef DP_STAMP
@@ -478,9 +510,9 @@ int launch_wsr_r(WsrArgs a, hipStream_t stream) {
 #if DP_EXP & 16
   static unsigned long long* dbg = nullptr;
   const int nblk = a.n_pg * a.n_slices;
-  if (!dbg) (void)hipMalloc(&dbg, sizeof(unsigned long long) * 8 * 8 * 4096);
+  if (!dbg) (void)hipMalloc(&dbg, sizeof(unsigned long long) * 16 * 8 * 4096);
   a.dbg = dbg;
-  (void)hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 8 * 8 * nblk, stream);
+  (void)hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 16 * 8 * nblk, stream);
 #endif
   hipLaunchKernelGGL((conv3x3_wsr_kernel<T, C, RP, RELU, POST>), dim3(a.n_pg * a.n_slices), dim3(512), lds, stream, a);
 #if DP_EXP & 16
@@ -488,13 +520,13 @@ int launch_wsr_r(WsrArgs a, hipStream_t stream) {
     static int shown = 0;
     if (shown++ == 4) {   // a warm launch
       (void)hipStreamSynchronize(stream);
-      unsigned long long* hbuf = (unsigned long long*)malloc(sizeof(unsigned long long) * 64 * nblk);
-      (void)hipMemcpy(hbuf, dbg, sizeof(unsigned long long) * 64 * nblk, hipMemcpyDeviceToHost);
+      unsigned long long* hbuf = (unsigned long long*)malloc(sizeof(unsigned long long) * 128 * nblk);
+      (void)hipMemcpy(hbuf, dbg, sizeof(unsigned long long) * 128 * nblk, hipMemcpyDeviceToHost);
       for (int w = 0; w < 8; ++w) {
-        double sum[5] = {0, 0, 0, 0, 0}, n = 0;
-        for (int b = 0; b < nblk; ++b) { for (int k = 0; k < 5; ++k) sum[k] += (double)hbuf[(b * 8 + w) * 8 + k]; n += (double)hbuf[(b * 8 + w) * 8 + 5]; }
-        fprintf(stderr, "wsr wave %d: per step cycles: issue %.0f  mfma %.0f  epilogue %.0f  vmcnt/lgkm wait %.0f  barrier %.0f  (steps/wg %.1f)\n", w,
-                sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, n / nblk);
+        double sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, n = 0;
+        for (int b = 0; b < nblk; ++b) { for (int k = 0; k < 11; ++k) if (k != 5) sum[k] += (double)hbuf[(b * 8 + w) * 16 + k]; n += (double)hbuf[(b * 8 + w) * 16 + 5]; }
+        fprintf(stderr, "wsr wave %d: per step cycles: top %.0f  [ring addresses %.0f  fetch pieces %.0f  hand-over read %.0f  deferred stores %.0f  post loads + first reads %.0f]  loop %.0f  after the loop %.0f  vmcnt/lgkm wait %.0f  barrier %.0f  (steps/wg %.1f)\n", w,
+                sum[0] / n, sum[6] / n, sum[7] / n, sum[8] / n, sum[9] / n, sum[10] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, n / nblk);
       }
       free(hbuf);
     }
