@@ -100,6 +100,52 @@ __global__ __launch_bounds__(512, 2) void lds_mfma(const u32x4* __restrict__ src
   if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + wave] = t1 - t0;
 }
 
+// the 32x32x16 instruction (twice the FLOPs of 16x16x32 per instruction): R fragment reads per group of 9 MFMAs, as above
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int R, int AHEAD>
+__global__ __launch_bounds__(512, 2) void lds_mfma32(const u32x4* __restrict__ src, float* __restrict__ out, unsigned long long* __restrict__ cyc, int iters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 65536 / 16; i += blockDim.x) reinterpret_cast<u32x4*>(smem)[i] = src[i & 4095];
+  u32x4 a[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a[i] = src[(i * 64 + lane) & 4095];
+  __syncthreads();
+  const unsigned char* base = smem + wave * 8192 + lane * 16;
+  f32x16 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[i][k] = 0.f;
+  constexpr int NR = R == 0 ? 1 : R;
+  u32x4 bf[AHEAD + 1];
+#pragma unroll
+  for (int k = 0; k < AHEAD + 1; ++k) bf[k] = *reinterpret_cast<const u32x4*>(base + (k & 7) * 1024);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int g = 0; g < AHEAD + 1; ++g) {
+#pragma unroll
+      for (int m = 0; m < 9; ++m) {
+        const int fi = g * NR + (m * NR) / 9;
+        const bool newfrag = R > 0 && (m == 0 || (m * NR) / 9 != ((m - 1) * NR) / 9);
+        if (newfrag) bf[(fi + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const u32x4*>(base + ((fi + AHEAD + it) & 7) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[m % 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[m]), __builtin_bit_cast(bf16x8, bf[fi % (AHEAD + 1)]), acc[m % 3], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += acc[i][k];
+  out[blockIdx.x * blockDim.x + tid] = sum;
+  if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + wave] = t1 - t0;
+}
+
 static double median_cycles(unsigned long long* cyc, int n) {
   std::vector<unsigned long long> h(n);
   hipMemcpy(h.data(), cyc, n * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -131,5 +177,11 @@ int main() {
   MIX(0, 6, 512, 0) MIX(1, 6, 512, 0) MIX(3, 6, 512, 0) MIX(5, 6, 512, 0) MIX(9, 6, 512, 0)
   MIX(0, 6, 256, 0) MIX(3, 6, 256, 0) MIX(5, 6, 256, 0) MIX(9, 6, 256, 0) MIX(5, 12, 256, 0) MIX(9, 12, 256, 0) MIX(5, 3, 256, 0) MIX(5, 3, 512, 0)
   MIX(5, 6, 512, 1) MIX(5, 12, 512, 1) MIX(9, 6, 512, 1) MIX(5, 6, 256, 1) MIX(5, 12, 256, 1) MIX(5, 6, 512, 3) MIX(3, 6, 512, 3) MIX(3, 6, 512, 4) MIX(5, 6, 512, 5)
+#define MIX32(R, A, T) { hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_mfma32<R, A>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((lds_mfma32<R, A>), dim3(cus), dim3(T), 65536, 0, src, out, cyc, iters); hipDeviceSynchronize(); \
+    const double c = median_cycles(cyc, cus * (T / 64)); const int wps = T / 256; \
+    printf("32x32x16: %d wave(s) per SIMD, %d fragment reads per 9 MFMAs, %2d ahead: %.2f cycles per MFMA and SIMD (= %.2f per 16x16x32's worth of FLOPs)\n", wps, R, A, \
+           c / (iters * 9.0 * (A + 1) * wps), c / (iters * 9.0 * (A + 1) * wps) / 2); }
+  MIX32(0, 6, 512) MIX32(3, 6, 512) MIX32(9, 6, 512) MIX32(9, 6, 256) MIX32(9, 3, 256)
   return 0;
 }
