@@ -125,6 +125,9 @@ __device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
 // dp_conv_ws.hip: the weight-stationary 3x3 kernel (128 -> 128 and 256 -> 256 channels) behind dp_conv2d_nhwc (kernel class 6)
 bool dp_conv_wsr_ok(const dp_conv_params* p);
 int dp_conv_wsr_launch(const dp_conv_params* p, dp_stream_t stream);
+// dp_conv_wq.hip: the weight-stationary 3x3 kernel on v_mfma_f32_32x32x16, one wave per SIMD (256 -> 256 channels; kernel class 10)
+bool dp_conv_wsq_ok(const dp_conv_params* p);
+int dp_conv_wsq_launch(const dp_conv_params* p, dp_stream_t stream);
 // dp_conv_rows.hip: the row-streaming K-split weight-stationary 3x3 kernel (512 / 256 input channels) behind dp_conv2d_nhwc (kernel class 7)
 bool dp_conv_rows_ok(const dp_conv_params* p);
 bool dp_conv_rows2_ok(const dp_conv_params* p);     // its 32-pixel form (kernel class 8)

@@ -1093,7 +1093,7 @@ int launch_conv_stream(const ConvArgs& a, hipStream_t stream) {
 // the 256x256 ring tile is ~1.15x the 128x128 ring tile when both fill the chip, so the shape is picked by
 // wave-quantisation efficiency (workgroups / (CUs x resident workgroups per CU), rounded up to whole rounds);
 // short-K layers are HBM/latency bound and run on the generic kernel with 64-byte steps (4 workgroups per CU).
-enum { DP_CONV_K64 = 0, DP_CONV_K128 = 1, DP_CONV_RING256 = 2, DP_CONV_RING128 = 3, DP_CONV_RING256x128 = 4, DP_CONV_STREAM = 5, DP_CONV_WSR = 6, DP_CONV_ROWS = 7, DP_CONV_ROWS2 = 8, DP_CONV_PWS = 9 };
+enum { DP_CONV_K64 = 0, DP_CONV_K128 = 1, DP_CONV_RING256 = 2, DP_CONV_RING128 = 3, DP_CONV_RING256x128 = 4, DP_CONV_STREAM = 5, DP_CONV_WSR = 6, DP_CONV_ROWS = 7, DP_CONV_ROWS2 = 8, DP_CONV_PWS = 9, DP_CONV_WSQ = 10 };
 
 static int num_cus() {
   static int n = 0;
@@ -1152,6 +1152,7 @@ static int choose_conv_kernel(const dp_conv_params* p, long long M) {
   }
   if (dp_conv_rows2_ok(p)) return DP_CONV_ROWS2;   // 3x3 with 512 input channels on maps whose width suits 32-pixel strips (DensePose head): dp_conv_rows.hip, third form
   if (dp_conv_rows_ok(p)) return DP_CONV_ROWS;     // 3x3 with 512 input channels (DensePose head, res5): row-streaming K-split weight-stationary kernel (dp_conv_rows.hip)
+  if (dp_conv_wsq_ok(p)) return DP_CONV_WSQ;       // 3x3 256 -> 256: weights stationary in registers, one wave per SIMD on v_mfma_f32_32x32x16 (dp_conv_wq.hip)
   if (dp_conv_wsr_ok(p)) return DP_CONV_WSR;       // 3x3 C -> C, C = 128 / 256: weights stationary in registers (dp_conv_ws.hip)
   if (dp_conv_pws_ok(p)) return DP_CONV_PWS;       // 1x1 with K = 512 / 1024 / 2048: weights stationary in registers, pixels once through LDS (dp_conv_pw.hip)
   if (stream_ok && pol.conv_stream != 0) return DP_CONV_STREAM;
@@ -1262,6 +1263,7 @@ extern "C" int dp_conv2d_tile_rows(const dp_conv_params* p) {
     case DP_CONV_RING256x128: return 256;
     case DP_CONV_STREAM: return 32;
     case DP_CONV_WSR: return 16;
+    case DP_CONV_WSQ: return 16;
     case DP_CONV_ROWS: return 16;
     case DP_CONV_ROWS2: return 32;
     case DP_CONV_PWS: return p->Cin == 2048 ? 16 : 32;
@@ -1365,6 +1367,7 @@ extern "C" int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream) {
   }
   if (kc == DP_CONV_ROWS || kc == DP_CONV_ROWS2) return dp_conv_rows_launch(p, stream);
   if (kc == DP_CONV_WSR) return dp_conv_wsr_launch(p, stream);
+  if (kc == DP_CONV_WSQ) return dp_conv_wsq_launch(p, stream);
   if (kc == DP_CONV_PWS) return dp_conv_pws_launch(p, stream);
   if (p->post_res || p->post_mode)
     return dp_fail(DP_ERR_UNSUPPORTED, "dp_conv2d_nhwc: post_res (a tensor added after the activation) is implemented by the weight-stationary 3x3 kernel only "

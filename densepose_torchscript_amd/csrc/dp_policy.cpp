@@ -21,6 +21,8 @@ const Key kKeys[] = {
     {"ws_over_shared", &DpPolicy::ws_over_shared},
     {"ws_over_alone", &DpPolicy::ws_over_alone},
     {"ws_reserve", &DpPolicy::ws_reserve},
+    {"conv_wsq", &DpPolicy::conv_wsq},
+    {"wsq_min_hw", &DpPolicy::wsq_min_hw},
     {"conv_rows", &DpPolicy::conv_rows},
     {"conv_rows2", &DpPolicy::conv_rows2},
     {"conv_rows2_256", &DpPolicy::conv_rows2_256},

@@ -17,6 +17,9 @@ struct DpPolicy {
   int64_t conv_ws = 1;              // 0 never, 4 only launches that have the chip to themselves
   int64_t ws_min_m = 256;           // fewest output pixels the kernel takes
   int64_t ws_over_shared = 2, ws_over_alone = 1, ws_reserve = 1;   // workgroups per CU slot with / without a neighbour stream, CU groups left free
+  // weight-stationary 3x3 on v_mfma_f32_32x32x16, one wave per SIMD (dp_conv_wq.hip)
+  int64_t conv_wsq = 1;             // 0 = never chosen (256 -> 256 layers then run on the kernels above)
+  int64_t wsq_min_hw = 128;         // fewest output pixels PER IMAGE the kernel takes (never a function of the batch)
   // row kernels (dp_conv_rows.hip)
   int64_t conv_rows = 1;            // 0 never, 2 the 16-pixel form also for n_dev launches and 256 -> 512
   int64_t conv_rows2 = 1;           // 0 = the 32-pixel form is never chosen

@@ -271,7 +271,7 @@ class Engine:
             e0.record(torch.cuda.current_stream(self.device))
             L.check(self.lib.dp_conv2d_nhwc(C.byref(p), self._stream()), "dp_conv2d_nhwc[%s]" % layer.name)
             e1.record(torch.cuda.current_stream(self.device))
-            cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_ring_kernel<256x256>", "conv_ring_kernel<128x128>", "conv_ring2_kernel<256x128>", "conv1x1_stream_kernel", "conv3x3_wsr_kernel", "conv3x3_rows_kernel", "conv3x3_rows2_kernel", "conv1x1_pws_kernel")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
+            cls = ("conv_igemm_kernel<64>", "conv_igemm_kernel<128>", "conv_ring_kernel<256x256>", "conv_ring_kernel<128x128>", "conv_ring2_kernel<256x128>", "conv1x1_stream_kernel", "conv3x3_wsr_kernel", "conv3x3_rows_kernel", "conv3x3_rows2_kernel", "conv1x1_pws_kernel", "conv3x3_wsq_kernel")[self.lib.dp_conv2d_kernel_class(C.byref(p))]
             if cls.startswith("conv_ring_kernel<"):   # one template instance (= one rocprofv3 kernel name) per tile height
                 cls = "conv_ring_kernel<%dx%s" % (self.lib.dp_conv2d_tile_rows(C.byref(p)), cls.split("x")[1])
                 if in2 is not None:                   # ... and per source count (the two-source form is its own instance)
@@ -282,6 +282,8 @@ class Engine:
                 cls = "%s<%d>" % (cls, x.C)
             if cls == "conv1x1_pws_kernel":           # ... per K length for the weight-stationary pointwise kernel
                 cls = ("conv1x1_pwq_kernel<%d>" if x.C == 256 else "conv1x1_pws_kernel<%d>") % x.C
+            if cls == "conv3x3_wsq_kernel":
+                cls = "conv3x3_wsq_kernel<%s%s>" % ("relu" if relu else "linear", ",post%d" % post_mode if post is not None else "")
             if cls == "conv3x3_wsr_kernel":           # ... and per (channels, ReLU) for the weight-stationary kernel
                 cls = "conv3x3_wsr_kernel<%d,%s%s>" % (x.C, "relu" if relu else "linear", ",post%d" % post_mode if post is not None else "")
             es = x.t.element_size()

@@ -207,7 +207,7 @@ def build_library(force=False):
     digest = _source_digest()
     if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
         return LIB_PATH
-    subprocess.check_call(["make", "-C", CSRC, "-B"])
+    subprocess.check_call(["make", "-C", CSRC, "-B", "-j%d" % min(8, os.cpu_count() or 1)])
     with open(stamp, "w") as f:
         f.write(digest + "\n")
     return LIB_PATH

@@ -64,6 +64,62 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(const u32x4* __restrict__ sr
   if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 
+// 32x32x16 (round 6): 32 distinct A fragments, 2 B fragments, 2 accumulators of 16 registers - the operand pattern of conv3x3_wsq_kernel
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MMA32(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0)
+__global__ __launch_bounds__(512, 2) void mfma32_loop(const u32x4* __restrict__ src, float* __restrict__ out, unsigned long long* __restrict__ cyc, int iters) {
+  const int lane = threadIdx.x & 63;
+  u32x4 a[32], b[2];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) a[i] = src[(i * 64 + lane) & 4095];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) b[i] = src[(2048 + i * 64 + lane) & 4095];
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int f = 0; f < 32; ++f) {
+      MMA32(a[f], b[f & 1], acc[f & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += acc[i][e];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+void run32(int threads, const u32x4* src, float* out, unsigned long long* cyc, int cus) {
+  const int iters = 2000;
+  for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(mfma32_loop, dim3(cus), dim3(threads), 0, 0, src, out, cyc, iters);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL(mfma32_loop, dim3(cus), dim3(threads), 0, 0, src, out, cyc, iters);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const int nw = cus * threads / 64;
+  std::vector<unsigned long long> h(nw);
+  hipMemcpy(h.data(), cyc, nw * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  std::sort(h.begin(), h.end());
+  const double med = (double)h[nw / 2];
+  const double per_wave = med / (32.0 * iters);
+  const double tf = 2.0 * 32 * 32 * 16 * 32.0 * iters * nw / (ms * 1e-3) / 1e12;
+  printf("%-58s %d waves/SIMD: %6.2f cycles per MFMA in a wave's stream, %6.2f per MFMA on the SIMD, %7.0f TFLOP/s, clock %.2f GHz\n",
+         "5 v_mfma_f32_32x32x16_bf16: 32 distinct A, 2 B, 2 accumulators", threads / 256, per_wave, per_wave / (threads / 256), tf, med / (ms * 1e-3) / 1e9);
+}
+
 template <int V>
 void run(const char* what, int threads, const u32x4* src, float* out, unsigned long long* cyc, int cus) {
   const int iters = 2000;
@@ -104,6 +160,7 @@ int main() {
     run<2>("2 32 distinct A, 2 B, 16 accumulators", threads, src, out, cyc, cus);
     run<3>("3 variant 1 + s_nop 1 between the pairs", threads, src, out, cyc, cus);
     run<4>("4 roles swapped: B-side register varies, A fixed per pair", threads, src, out, cyc, cus);
+    run32(threads, src, out, cyc, cus);
   }
   return 0;
 }
