@@ -51,6 +51,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2w __attribute__((ext_vector_type(2)));
 
 template <typename T>
 struct Mma32;
@@ -87,6 +88,8 @@ struct WsqArgs {
   const void* post;            // dp_conv_params.post_res
   int Hl, Wl;                  // POST = 2: geometry of the half-size map
   unsigned post_bytes;
+  const int* n_dev;            // dp_conv_params.n_dev: only the first *n_dev - n0 of the N images of this launch hold data
+  int n0;
   unsigned long long* dbg;
 };
 
@@ -131,7 +134,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wsq_kernel(const WsqArgs p) {
   const int slice = (b >> 3) % p.n_slices;
   const int pg = (b & 7) + 8 * (b / (8 * p.n_slices));
 
-  const int s_begin = (int)((long long)p.S * pg / p.n_pg), s_end = (int)((long long)p.S * (pg + 1) / p.n_pg);
+  int S = p.S;
+  if (p.n_dev) S = min(max(*p.n_dev - p.n0, 0), p.N) * p.n_strips * p.spc;      // the live images only (uniform: a scalar load)
+  const int s_begin = (int)((long long)S * pg / p.n_pg), s_end = (int)((long long)S * (pg + 1) / p.n_pg);
   const int nst = s_end - s_begin;
   if (nst <= 0) return;
 
@@ -461,13 +466,338 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wsq_kernel(const WsqArgs p) {
 #undef DP_STAMP
 }
 
+
+// =====================================================================================================
+// The same structure on v_mfma_f32_16x16x32 (round 6, second form; profiles/r6_wsq_experiments.txt section 3). The chip holds ~2.0 GHz under
+// this instruction and ~1.78 under 32x32x16, which cost conv3x3_wsq_kernel what its structure gained. One wave per SIMD, 512 registers:
+//   * wave (g, h) holds couts [32 g, 32 g + 32) x channels [128 h, 128 h + 128) x 9 taps as 2 cout halves x 36 K planes of A fragments;
+//   * a step is four output rows of a 16-pixel strip; B fragment (channel block, input row q, column tap) = 16 pixels x 32 channels, read ONCE
+//     and used by every output row it feeds (kernel rows q - t in 0..2) and both cout halves: 72 fragment reads for 288 MFMAs
+//     (conv3x3_wsr_kernel: 120 for 216); input rows visited in the order 2, 0, 3, 5, 1, 4 so that the rows that feed one output row (two
+//     MFMAs per fragment) never sit next to each other in the stream - six fragments ahead then are at least 24 MFMAs ahead;
+//   * the wave finishes the cout half c' = 0 of its four rows itself and hands c' = 1 to its partner; its A rows are permuted so that c' = 0
+//     IS the half it keeps (A row r of half c' = cout 16 (c' ^ h) + r of the group): lane (pixel fr, quarter fq) stores couts 16 h + 4 fq + 0..3,
+//     8 bytes per row, the four lanes of a pixel 32 contiguous bytes;
+//   * ring pixels at pitch 544 (32-byte pad: chunk c of pixel p on 16-byte slot (2 p + c) mod 16, conflict-free for this fragment shape).
+// =====================================================================================================
+constexpr int kW1PP = 544;
+
 template <typename T, bool RELU, int POST>
+__global__ __launch_bounds__(256, 1) void conv3x3_ws1_kernel(const WsqArgs p) {
+  static_assert(sizeof(T) == 2, "16-bit storage only");
+  constexpr int RP = kWqRP, PIX = kWqPix, PP = kW1PP, PPR = kWqPPR, ROWB = kWqRowB, NSLOT = kWqSlots, XCH = kWqXch;
+  static_assert(18 * PP <= ROWB, "ring row");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int g = wave & 1, h = wave >> 1;            // cout group of 32, K half
+  const int b = blockIdx.x;
+  const int slice = (b >> 3) % p.n_slices;
+  const int pg = (b & 7) + 8 * (b / (8 * p.n_slices));
+
+  int S = p.S;
+  if (p.n_dev) S = min(max(*p.n_dev - p.n0, 0), p.N) * p.n_strips * p.spc;      // the live images only (uniform: a scalar load)
+  const int s_begin = (int)((long long)S * pg / p.n_pg), s_end = (int)((long long)S * (pg + 1) / p.n_pg);
+  const int nst = s_end - s_begin;
+  if (nst <= 0) return;
+
+  const int cgrp = slice * 64 + g * 32;
+  u32x4 wq[72];       // [cout half c'][plane s = channel block x tap]
+  {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int L = cgrp + 16 * (c ^ h) + fr, l64 = L & 63;
+      const int rem = l64 & 31;
+      const int phys = (L & ~63) + (((l64 >> 5) * 2 + ((rem >> 2) & 1)) * 16) + (rem >> 3) * 4 + (rem & 3);   // pack.py's row permutation
+      const unsigned char* __restrict__ w = reinterpret_cast<const unsigned char*>(p.w) + dp_wtile_off(phys, h * 36, fq, 72);
+#pragma unroll
+      for (int s = 0; s < 36; ++s) wq[c * 36 + s] = *reinterpret_cast<const u32x4*>(w + s * 1024);
+    }
+#pragma unroll
+    for (int s = 0; s < 72; ++s) {      // register classes pinned once (see conv3x3_wsq_kernel)
+      if (s < kWqAgprFrags) asm volatile("" : "+a"(wq[s]));
+      else asm volatile("" : "+v"(wq[s]));
+    }
+  }
+  // initial accumulator values: the bias in the h = 0 wave (half c', register e = cout 16 c' + 4 fq + e of the group), zero in the other
+  f32x4 binit[2];
+  {
+    const float m = h == 0 ? 1.f : 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) binit[c] = *reinterpret_cast<const f32x4*>(p.bias + cgrp + 16 * c + 4 * fq) * m;
+  }
+
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_post = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(POST ? p.post : p.in), 0, POST ? p.post_bytes : 0u, 0x00020000);
+
+  const int frag_lane = fr * PP + h * 256 + fq * 16;
+  const int n_cols = p.n_strips * 16;
+  const int opix = p.cout * 2;
+  const int ocb = (cgrp + 16 * h + 4 * fq) * 2;             // byte offset of this lane's 4 output channels inside a pixel
+
+  auto advance = [&](WsqStep& st) __attribute__((always_inline)) {
+    st.r += RP; st.um += RP; st.first = 0;
+    if (st.r >= p.H) {
+      st.r = 0; st.um += 2; st.first = 1; st.c0 += 16;
+      if (st.c0 >= n_cols) { st.c0 = 0; st.n += 1; }
+    }
+    if (st.um >= NSLOT) st.um -= NSLOT;
+  };
+  unsigned dl[PPR];
+  auto lanes_for_strip = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int pr = 0; pr < PPR; ++pr) {
+      const int gi = pr * 64 + lane, px = gi / 34, sub = gi - px * 34;
+      const bool ok = px < 18 && sub < 32 && (unsigned)(c0 - 1 + px) < (unsigned)p.W;
+      dl[pr] = ok ? (unsigned)(px * PIX + sub * 16) : kLaneInv;
+    }
+  };
+  auto row_base = [&](const WsqStep& st, int q, bool live) __attribute__((always_inline)) -> unsigned {
+    const int row = st.r - 1 + q;
+    return (live && (unsigned)row < (unsigned)p.H) ? (unsigned)(((st.n * p.H + row) * p.W + st.c0 - 1) * PIX) : kRowInv;
+  };
+  auto slot_of = [&](const WsqStep& st, int q) __attribute__((always_inline)) -> int {
+    int s = st.um + q;
+    if (s >= NSLOT) s -= NSLOT;
+    return s;
+  };
+  auto fetch_piece = [&](int slot_bytes, unsigned rbase, auto prr) __attribute__((always_inline)) {
+    constexpr int pr = decltype(prr)::value;
+    if constexpr (!(DP_WSQ_EXP & 8))
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, DP_LDS_PTR(smem + slot_bytes + pr * 1024), 16, (int)(dl[pr] + rbase), 0, 0, 0);
+  };
+  auto fetch_head_rows = [&](const WsqStep& st, bool live) __attribute__((always_inline)) {
+    const int q = wave & 1;
+    const int sb = slot_of(st, q) * ROWB;
+    const unsigned rb = row_base(st, q, live);
+    if (wave < 2) static_for<0, 5>([&](auto prr) { fetch_piece(sb, rb, prr); });
+    else static_for<5, 10>([&](auto prr) { fetch_piece(sb, rb, prr); });
+  };
+
+  WsqStep st_c, st_n;
+  {
+    const int colid = s_begin / p.spc, k = s_begin - colid * p.spc;
+    st_c.n = colid / p.n_strips;
+    st_c.c0 = (colid - st_c.n * p.n_strips) * 16;
+    st_c.r = k * RP;
+    st_c.um = 0;
+    st_c.first = 1;
+  }
+  lanes_for_strip(st_c.c0);
+  fetch_head_rows(st_c, true);
+  {
+    const int sb = slot_of(st_c, 2 + wave) * ROWB;
+    const unsigned rb = row_base(st_c, 2 + wave, true);
+    static_for<0, PPR>([&](auto prr) { fetch_piece(sb, rb, prr); });
+  }
+  st_n = st_c;
+  advance(st_n);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- pending epilogue (the step computed in the previous iteration): the kept cout half of the four rows, where they go
+  f32x4 eacc[4];
+  int e_off = 0, e_rows = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) eacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // post tensor values of the pending step. POST = 1: the lane's 4 channels at its pixel of each row. POST = 2: the four half-size
+  // neighbours of its pixel of each row (two source rows, wave-uniform, x two source columns) + the weights.
+  constexpr int NPV = POST == 1 ? 4 : (POST == 2 ? 16 : 1);
+  constexpr int NPL = POST == 1 ? 4 : (POST == 2 ? 16 : 0);
+  u32x2w pv[NPV];
+#pragma unroll
+  for (int k = 0; k < NPV; ++k) pv[k] = u32x2w{0u, 0u};
+  float p_lx = 0.f, p_ly[4] = {0.f, 0.f, 0.f, 0.f};
+  auto post_issue = [&](const WsqStep& st) __attribute__((always_inline)) {
+    const int col = st.c0 + fr;
+    if constexpr (POST == 1) {
+      const int off = ((st.n * p.H + st.r) * p.W + col) * opix + ocb;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        pv[t] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, (st.r + t < p.H && col < p.W) ? off + t * (p.W * opix) : (int)kLaneInv, 0, 0);
+    } else if constexpr (POST == 2) {
+      int x0, x1;
+      wq_bil_src(min(col, p.W - 1), p.Wl, x0, x1, p_lx);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        int y0, y1;
+        wq_bil_src(min(st.r + t, p.H - 1), p.Hl, y0, y1, p_ly[t]);       // wave-uniform
+        const int o0 = ((st.n * p.Hl + y0) * p.Wl) * opix + ocb, o1 = ((st.n * p.Hl + y1) * p.Wl) * opix + ocb;
+        pv[4 * t + 0] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, o0 + x0 * opix, 0, 0);
+        pv[4 * t + 1] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, o0 + x1 * opix, 0, 0);
+        pv[4 * t + 2] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, o1 + x0 * opix, 0, 0);
+        pv[4 * t + 3] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, o1 + x1 * opix, 0, 0);
+      }
+    }
+  };
+  auto epi_prepare = [&]() __attribute__((always_inline)) {};
+  f32x4 eo[4];
+  auto epi_read = [&](int par, auto tt) __attribute__((always_inline)) {
+    constexpr int t = decltype(tt)::value;
+    eo[t] = *reinterpret_cast<const f32x4*>(smem + XCH + ((((wave ^ 2) * 2 + par) * 4 + t)) * 1024 + lane * 16);
+  };
+  auto epi_store = [&](auto tt) __attribute__((always_inline)) {
+    constexpr int t = decltype(tt)::value;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = eacc[t][e] + eo[t][e];
+      if constexpr (RELU) v[e] = fmaxf(v[e], 0.f);
+    }
+    if constexpr (POST == 1) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        v[2 * e] += Elem<T>::unpack(pv[t][e] & 0xffffu);
+        v[2 * e + 1] += Elem<T>::unpack(pv[t][e] >> 16);
+      }
+    } else if constexpr (POST == 2) {
+      const float hx = 1.f - p_lx, hy = 1.f - p_ly[t];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int sh = (e & 1) * 16;
+        const float a = Elem<T>::unpack((pv[4 * t + 0][e >> 1] >> sh) & 0xffffu), bb = Elem<T>::unpack((pv[4 * t + 1][e >> 1] >> sh) & 0xffffu);
+        const float c = Elem<T>::unpack((pv[4 * t + 2][e >> 1] >> sh) & 0xffffu), d = Elem<T>::unpack((pv[4 * t + 3][e >> 1] >> sh) & 0xffffu);
+        v[e] += hy * (hx * a + p_lx * bb) + p_ly[t] * (hx * c + p_lx * d);     // ATen's order
+      }
+    }
+    const u32x2w pk = {Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3])};
+    __builtin_amdgcn_raw_buffer_store_b64(pk, rs_out, t < e_rows ? e_off + t * (p.W * opix) : (int)kLaneInv, 0, 0);
+  };
+
+  unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define DP_STAMP(k) if constexpr (DP_WSQ_EXP & 16) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - tl; tl = t_; }
+  unsigned long long tl = (DP_WSQ_EXP & 16) ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long t_loop0 = tl, rt0 = (DP_WSQ_EXP & 16) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+
+  // ---- loop state, one step ahead of its use (computed inside the previous step's matrix loop)
+  auto frag_bases = [&](const WsqStep& st, int (&v)[6]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) v[q] = slot_of(st, q) * ROWB + frag_lane;
+  };
+  int va[6], va_n[6];
+  frag_bases(st_c, va);
+  int nsb = slot_of(st_n, 2 + wave) * ROWB, nsb_n = 0;
+  unsigned nrb = row_base(st_n, 2 + wave, nst > 1), nrb_n = 0;
+  bool n_first = nst > 1 && st_n.first;
+  constexpr int NF = 72, AHEAD = DP_WSQ_AHEAD, DMA_GAP = 3;
+  // fragment f = (channel block cbl of 32, position in the row order, column tap dx)
+  constexpr int kRowOrder[6] = {2, 0, 3, 5, 1, 4};
+
+  for (int i = 0; i < nst; ++i) {
+    const int par = i & 1;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc[t][0] = binit[0]; acc[t][1] = binit[1]; }
+    auto frag = [&](auto ff) __attribute__((always_inline)) -> u32x4 {
+      constexpr int f = decltype(ff)::value;
+      constexpr int cbl = f / 18, q = kRowOrder[(f % 18) / 3], dx = f % 3;
+      return *reinterpret_cast<const u32x4*>(smem + va[q] + (dx * PP + cbl * 64));
+    };
+    u32x4 bf[AHEAD + 1];
+    static_for<0, AHEAD>([&](auto ff) { bf[decltype(ff)::value] = frag(ff); });
+    __builtin_amdgcn_sched_barrier(0);
+    DP_STAMP(0)
+    static_for<0, NF>([&](auto ff) {
+      constexpr int f = decltype(ff)::value;
+      constexpr int cbl = f / 18, q = kRowOrder[(f % 18) / 3], dx = f % 3;
+      if constexpr (f + AHEAD < NF && !(DP_WSQ_EXP & 1)) bf[(f + AHEAD) % (AHEAD + 1)] = frag(std::integral_constant<int, (f + AHEAD < NF ? f + AHEAD : 0)>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((DP_WSQ_EXP & 32) && f % 18 == 0 && f > 0) { DP_STAMP(7 + f / 18) }
+      // ---- side work in the MFMAs' shadow
+      if constexpr (f == 0) {               // the next step starts a column: lane offsets of its strip, its two head rows
+        if (n_first) {
+          lanes_for_strip(st_n.c0);
+          fetch_head_rows(st_n, true);
+        }
+      }
+      if constexpr (f >= 1 && f < 1 + DMA_GAP * PPR && (f - 1) % DMA_GAP == 0) fetch_piece(nsb, nrb, std::integral_constant<int, (f >= 1 && f < 1 + DMA_GAP * PPR ? (f - 1) / DMA_GAP : 0)>{});
+      if constexpr (f == 32) { epi_read(par ^ 1, std::integral_constant<int, 0>{}); epi_read(par ^ 1, std::integral_constant<int, 1>{}); }
+      if constexpr (f == 33) { epi_read(par ^ 1, std::integral_constant<int, 2>{}); epi_read(par ^ 1, std::integral_constant<int, 3>{}); }
+      if constexpr (f == 36) epi_prepare();
+      if constexpr (f == 38) epi_store(std::integral_constant<int, 0>{});
+      if constexpr (f == 42) epi_store(std::integral_constant<int, 1>{});
+      if constexpr (f == 46) epi_store(std::integral_constant<int, 2>{});
+      if constexpr (f == 50) epi_store(std::integral_constant<int, 3>{});
+      if constexpr (f == 53 && POST != 0) post_issue(st_c);
+      if constexpr (f == 54) {              // where this step's outputs go (its epilogue runs inside the next step)
+        const int col = st_c.c0 + fr;
+        e_off = ((st_c.n * p.H + st_c.r) * p.W + col) * opix + ocb;
+        e_rows = col < p.W ? p.H - st_c.r : 0;
+      }
+      if constexpr (f == 56) { st_c = st_n; advance(st_n); }
+      if constexpr (f == 58) frag_bases(st_c, va_n);
+      if constexpr (f == 60) {
+        nsb_n = slot_of(st_n, 2 + wave) * ROWB;
+        nrb_n = row_base(st_n, 2 + wave, i + 2 < nst);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- input row q feeds output row t with kernel row q - t, both cout halves
+      static_for<0, 4>([&](auto tt) {
+        constexpr int t = decltype(tt)::value;
+        if constexpr (q - t >= 0 && q - t <= 2) {
+          static_for<0, 2>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (!(DP_WSQ_EXP & 4)) Mma<T>::run(wq[c * 36 + cbl * 9 + (q - t) * 3 + dx], bf[f % (AHEAD + 1)], acc[t][c]);
+            else acc[t][c][0] += __builtin_bit_cast(float, bf[f % (AHEAD + 1)][0]) * __builtin_bit_cast(float, wq[c * 36 + cbl * 9 + (q - t) * 3 + dx][0]);
+          });
+        }
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (DP_WSQ_EXP & 32) { DP_STAMP(11) } else { DP_STAMP(1) }
+    // ---- hand cout half 1 of the four rows to the partner, keep half 0 for the epilogue that runs inside the next step
+    {
+      unsigned char* xb = smem + XCH + ((wave * 2 + par) * 4) * 1024 + lane * 16;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        *reinterpret_cast<f32x4*>(xb + t * 1024) = acc[t][1];
+        eacc[t] = acc[t][0];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) va[q] = va_n[q];
+    nsb = nsb_n; nrb = nrb_n;
+    n_first = i + 2 < nst && st_n.first;
+    DP_STAMP(2)
+    // the rows fetched in this iteration have landed: every fetch is older than this iteration's four stores (and post loads)
+    if constexpr (NPL == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (NPL == 16) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DP_STAMP(3)
+    __builtin_amdgcn_s_barrier();
+    DP_STAMP(4)
+  }
+  // ---- drain: the last step's epilogue
+  static_for<0, 4>([&](auto tt) { epi_read((nst - 1) & 1, tt); });
+  epi_prepare();
+  static_for<0, 4>([&](auto tt) { epi_store(tt); });
+  if constexpr (DP_WSQ_EXP & 16) {
+    if (lane == 0 && p.dbg) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) p.dbg[(blockIdx.x * 4 + wave) * 16 + k] = ph[k];
+      p.dbg[(blockIdx.x * 4 + wave) * 16 + 5] = nst;
+#pragma unroll
+      for (int k = 8; k < 12; ++k) p.dbg[(blockIdx.x * 4 + wave) * 16 + k] = ph[k];
+      p.dbg[(blockIdx.x * 4 + wave) * 16 + 6] = __builtin_amdgcn_s_memtime() - t_loop0;
+      p.dbg[(blockIdx.x * 4 + wave) * 16 + 7] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+  }
+#undef DP_STAMP
+}
+
+template <typename T, bool RELU, int POST, int SH>
 int launch_wsq_r(WsqArgs a, int over, hipStream_t stream) {
   static_assert(kWqLds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   static int cus = 0;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wsq_kernel<T, RELU, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, kWqLds);
+    if constexpr (SH == 32) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wsq_kernel<T, RELU, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, kWqLds);
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_ws1_kernel<T, RELU, POST>), hipFuncAttributeMaxDynamicSharedMemorySize, kWqLds);
     cus = wq_num_cus();
     attr_set = true;
   }
@@ -487,7 +817,8 @@ int launch_wsq_r(WsqArgs a, int over, hipStream_t stream) {
   a.dbg = dbg;
   (void)hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 16 * 4 * nblk, stream);
 #endif
-  hipLaunchKernelGGL((conv3x3_wsq_kernel<T, RELU, POST>), dim3(a.n_pg * a.n_slices), dim3(256), kWqLds, stream, a);
+  if constexpr (SH == 32) hipLaunchKernelGGL((conv3x3_wsq_kernel<T, RELU, POST>), dim3(a.n_pg * a.n_slices), dim3(256), kWqLds, stream, a);
+  else hipLaunchKernelGGL((conv3x3_ws1_kernel<T, RELU, POST>), dim3(a.n_pg * a.n_slices), dim3(256), kWqLds, stream, a);
 #if DP_WSQ_EXP & 16
   {
     static int shown = 0;
@@ -504,7 +835,7 @@ int launch_wsq_r(WsqArgs a, int over, hipStream_t stream) {
         if (DP_WSQ_EXP & 32) {
           double q4[4] = {0, 0, 0, 0};
           for (int b = 0; b < nblk; ++b) for (int k = 0; k < 4; ++k) q4[k] += (double)hbuf[(b * 4 + w) * 16 + 8 + k];
-          fprintf(stderr, "wsq wave %d: loop quarters (24 fragments = 36 MFMAs = 1152 pipe cycles each): %.0f %.0f %.0f %.0f\n", w, q4[0] / n, q4[1] / n, q4[2] / n, q4[3] / n);
+          fprintf(stderr, "wsq wave %d: loop quarters (1152 pipe cycles each): %.0f %.0f %.0f %.0f\n", w, q4[0] / n, q4[1] / n, q4[2] / n, q4[3] / n);
         }
         fprintf(stderr, "wsq wave %d: per step cycles: top %.0f  loop %.0f  hand-over %.0f  waits %.0f  barrier %.0f  (steps/wg %.1f, in-kernel clock %.2f GHz)\n", w,
                 sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, n / nblk, cyc / (rt * 10.0));
@@ -516,12 +847,12 @@ int launch_wsq_r(WsqArgs a, int over, hipStream_t stream) {
   return dp_check_launch("conv3x3_wsq_kernel");
 }
 
-template <typename T>
+template <typename T, int SH>
 int launch_wsq(const WsqArgs& a, int over, hipStream_t stream, int relu, int post_mode) {
-  if (post_mode == 1 && relu) return launch_wsq_r<T, true, 1>(a, over, stream);
-  if (post_mode == 2 && relu) return launch_wsq_r<T, true, 2>(a, over, stream);
+  if (post_mode == 1 && relu) return launch_wsq_r<T, true, 1, SH>(a, over, stream);
+  if (post_mode == 2 && relu) return launch_wsq_r<T, true, 2, SH>(a, over, stream);
   if (post_mode != 0) return dp_fail(DP_ERR_UNSUPPORTED, "conv3x3_wsq_kernel: post_res needs ReLU");
-  return relu ? launch_wsq_r<T, true, 0>(a, over, stream) : launch_wsq_r<T, false, 0>(a, over, stream);
+  return relu ? launch_wsq_r<T, true, 0, SH>(a, over, stream) : launch_wsq_r<T, false, 0, SH>(a, over, stream);
 }
 
 }  // namespace
@@ -530,9 +861,9 @@ int launch_wsq(const WsqArgs& a, int over, hipStream_t stream, int relu, int pos
 // The answer depends on the layer and the per-image geometry only - never on N.
 bool dp_conv_wsq_ok(const dp_conv_params* p) {
   const DpPolicy& pol = dp_policy();
-  if (pol.conv_wsq == 0) return false;
+  if (pol.conv_wsq == 0 || p->ring_order) return false;
   const bool shape = p->Cin == 256 && p->Cout == 256 && p->Cout_w == 256;
-  return (p->dtype == DP_BF16 || p->dtype == DP_F16) && !p->n_dev && shape && p->ntaps == 9 && p->Kpad == 9 * p->Cin && p->stride == 1 &&
+  return (p->dtype == DP_BF16 || p->dtype == DP_F16) && shape && p->ntaps == 9 && p->Kpad == 9 * p->Cin && p->stride == 1 &&
          (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == -1 && p->wi_off == -1 && p->H == p->Ho && p->W == p->Wo &&
          !p->residual && !p->out_f32 && !p->head_out && !p->in2 && p->n_groups <= 1 && p->out && p->osW == p->Cout &&
          p->osH == (long long)p->W * p->Cout && p->osN == (long long)p->H * p->W * p->Cout &&
@@ -564,13 +895,16 @@ int dp_conv_wsq_launch(const dp_conv_params* p, dp_stream_t stream) {
     a.N = n; a.H = p->H; a.W = p->W; a.cout = p->Cout;
     a.n_strips = a.spc = a.n_slices = a.n_pg = a.S = 0;
     a.dbg = nullptr;
+    a.n_dev = p->n_dev; a.n0 = n0;
     a.Hl = p->H / 2; a.Wl = p->W / 2;
     const long long post_img = pm == 2 ? (long long)a.Hl * a.Wl * 512 : per_img;
     a.post = p->post_res ? reinterpret_cast<const unsigned char*>(p->post_res) + (long long)n0 * post_img : nullptr;
     a.post_bytes = p->post_res ? (unsigned)(n * post_img) : 0u;
     a.in_bytes = (unsigned)(n * per_img);
     a.out_bytes = (unsigned)(n * per_img);
-    const int rc = p->dtype == DP_BF16 ? launch_wsq<uint16_t>(a, over, s, p->relu, pm) : launch_wsq<f16_t>(a, over, s, p->relu, pm);
+    int rc;
+    if (pol.wsq_shape == 32) rc = p->dtype == DP_BF16 ? launch_wsq<uint16_t, 32>(a, over, s, p->relu, pm) : launch_wsq<f16_t, 32>(a, over, s, p->relu, pm);
+    else rc = p->dtype == DP_BF16 ? launch_wsq<uint16_t, 16>(a, over, s, p->relu, pm) : launch_wsq<f16_t, 16>(a, over, s, p->relu, pm);
     if (rc != DP_OK) return rc;
   }
   return DP_OK;

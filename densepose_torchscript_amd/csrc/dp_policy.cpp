@@ -23,6 +23,7 @@ const Key kKeys[] = {
     {"ws_reserve", &DpPolicy::ws_reserve},
     {"conv_wsq", &DpPolicy::conv_wsq},
     {"wsq_min_hw", &DpPolicy::wsq_min_hw},
+    {"wsq_shape", &DpPolicy::wsq_shape},
     {"conv_rows", &DpPolicy::conv_rows},
     {"conv_rows2", &DpPolicy::conv_rows2},
     {"conv_rows2_256", &DpPolicy::conv_rows2_256},

@@ -19,6 +19,7 @@ struct DpPolicy {
   int64_t ws_over_shared = 2, ws_over_alone = 1, ws_reserve = 1;   // workgroups per CU slot with / without a neighbour stream, CU groups left free
   // weight-stationary 3x3 on v_mfma_f32_32x32x16, one wave per SIMD (dp_conv_wq.hip)
   int64_t conv_wsq = 1;             // 0 = never chosen (256 -> 256 layers then run on the kernels above)
+  int64_t wsq_shape = 16;           // 16 = conv3x3_ws1_kernel (v_mfma_f32_16x16x32), 32 = conv3x3_wsq_kernel (v_mfma_f32_32x32x16): different summation orders
   int64_t wsq_min_hw = 128;         // fewest output pixels PER IMAGE the kernel takes (never a function of the batch)
   // row kernels (dp_conv_rows.hip)
   int64_t conv_rows = 1;            // 0 never, 2 the 16-pixel form also for n_dev launches and 256 -> 512

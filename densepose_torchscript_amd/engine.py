@@ -167,7 +167,7 @@ class Engine:
         return torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
 
     def conv(self, layer, x, relu=False, residual=None, rshift=0, out_f32=False, out=None, out_c_stride=None, out_c_off=0,
-             out_geom=None, out_hw=None, head=None, post=None, post_mode=0, n_dev=None, in2=None, groups=None):
+             out_geom=None, out_hw=None, head=None, post=None, post_mode=0, n_dev=None, in2=None, groups=None, ring_order=False):
         """x: Act. Returns Act. out_geom: (osN, osH, osW, base_elems) override for the sub-pixel deconv; out_hw: (Ho, Wo)
         override (the paired-pixel stem, whose input is narrower than its output is wide). head: (weight [16, Cout], bias [16],
         macs per pixel) of a fused 1x1 head on this layer's ReLU output - the call then returns the HEAD's fp32 output
@@ -246,6 +246,7 @@ class Engine:
         p.out_f32 = 1 if out_f32 else 0
         p.hi_off, p.wi_off = layer.hi_off, layer.wi_off
         p.shared_chip = int(self._shared_chip)
+        p.ring_order = 1 if ring_order else 0      # dp_conv_params.ring_order: the bits of the LDS-ring family whatever the batch
         if n_dev is not None:
             p.n_dev = n_dev.data_ptr()
         if post is not None:
@@ -372,7 +373,7 @@ class Engine:
         p.out = 4096                      # placeholders: only NULL / non-NULL matters to the class query
         p.post_res, p.post_mode = 4096, post_mode
         p.shared_chip = int(self._shared_chip)
-        return self.lib.dp_conv2d_kernel_class(C.byref(p)) == 6
+        return self.lib.dp_conv2d_kernel_class(C.byref(p)) in (6, 10)
 
     def bottleneck_tail(self, l2, l3, l1n, t1, residual, sc_in=None):
         """conv2 -> conv3 (+ residual, ReLU) -> conv1 of the next block in one launch (dp_bottleneck_tail_nhwc).
@@ -613,7 +614,8 @@ class Engine:
             if hp is not None and self.head_fusable(Ls["rpn_conv"], f):
                 # 3x3 conv + ReLU + the two 1x1 heads in one launch: the 256-channel hidden tensor is never written (rpn.py:168-171)
                 return self.conv(Ls["rpn_conv"], f, relu=True, head=(hp[0], hp[1], Ls["rpn_head"].macs_per_pixel))
-            t = self.conv(Ls["rpn_conv"], f, relu=True)
+            # (a launch too small for the fused form: the same K order as the fused one - which of the two runs depends on the batch)
+            t = self.conv(Ls["rpn_conv"], f, relu=True, ring_order=True)
             return self.conv(Ls["rpn_head"], t, out_f32=True)
 
         # the five levels are independent (same weights, rpn.py:160-172): p2 on this stream, the small ones beside it

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("DP_HIP_LIB") or os.path.join(_HERE, "libdensepose_hip
 CSRC = os.path.join(_HERE, "csrc")
 
 DP_F32, DP_BF16, DP_F16 = 0, 1, 2
-ABI_VERSION = 7   # == DP_ABI_VERSION of include/densepose_hip.h (bumped whenever a params struct or the symbol set changes)
+ABI_VERSION = 8   # == DP_ABI_VERSION of include/densepose_hip.h (bumped whenever a params struct or the symbol set changes)
 
 # user-facing dtype names -> (enum, element size)
 DTYPES = {"fp32": DP_F32, "float32": DP_F32, "bf16": DP_BF16, "bfloat16": DP_BF16, "fp16": DP_F16, "float16": DP_F16, "half": DP_F16}
@@ -40,7 +40,8 @@ class ConvParams(C.Structure):
                 ("shared_chip", c_i32), ("post_mode", c_i32), ("post_res", c_void_p), ("n_dev", c_void_p),
                 ("in2", c_void_p), ("H2", c_i32), ("W2", c_i32), ("Cin2", c_i32), ("stride2", c_i32),
                 ("split_k", c_i32), ("split_ws", c_void_p),
-                ("n_groups", c_i32), ("weight_g", c_void_p * 4), ("ktab_g", c_void_p * 4), ("out_g", c_void_p * 4)]
+                ("n_groups", c_i32), ("weight_g", c_void_p * 4), ("ktab_g", c_void_p * 4), ("out_g", c_void_p * 4),
+                ("ring_order", c_i32)]
 
 
 class BottleneckParams(C.Structure):

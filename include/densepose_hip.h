@@ -37,7 +37,7 @@ enum dp_status {
   DP_ERR_LAUNCH = -3        /* hipGetLastError() after launch */
 };
 
-#define DP_ABI_VERSION 7
+#define DP_ABI_VERSION 8
 int dp_abi_version(void);
 /* human-readable reason of the last non-zero return on this thread */
 const char* dp_last_error(void);
@@ -133,8 +133,9 @@ typedef struct {
    * skipped (N keeps sizing the launch and the tensors). The DensePose head runs on R detected boxes (roi_head.py:126-158); R is
    * known on the device only - sizing its launches on the host costs a device -> host round trip in the middle of every step.
    * Rows behind *n_dev inside the last live tile are computed on whatever the input holds: every image (ROI) is independent,
-   * their outputs are never read. Honoured by the tiled kernels (classes 0 - 4) and classes 7 / 8; a launch with n_dev is never given to
-   * the persistent kernels that ignore it (classes 5 and 6: they would do the full work on all N images). */
+   * their outputs are never read. Honoured by the tiled kernels (classes 0 - 4) and classes 7 / 8 / 10 (which size their work from the live
+   * count and write nothing behind it); a launch with n_dev is never given to the persistent kernels that ignore it (classes 5 and 6: they
+   * would do the full work on all N images). */
   const int32_t* n_dev;
   /* Second source of a pointwise (1 tap, stride 1) layer: K = Cin channels of `in` followed by Cin2 channels of `in2`, an
    * [N, H2, W2, Cin2] tensor read at pixel (ho * stride2, wo * stride2); Kpad = Cin + Cin2, both multiples of 64 bytes; the
@@ -164,6 +165,12 @@ typedef struct {
   const void* weight_g[4];
   const int32_t* ktab_g[4];
   void* out_g[4];
+  /* Summation-order pin (ABI 8): 1 = this launch must produce the bits of the LDS-ring kernel family (classes 1 - 6 share one K
+   * order: 64-byte planes, channel block x tap, one chain). Kernel classes with an order of their own (10: the one-wave-per-SIMD
+   * weight-stationary 3x3 kernel) are then not chosen. For a caller that runs the SAME layer with a fused head - ring kernels only -
+   * whenever the launch is large enough and as a plain convolution otherwise (the RPN's 3x3, rpn.py:166-172): the fused / unfused
+   * choice depends on the batch, the bits of a frame must not. 0 = the library's choice. */
+  int32_t ring_order;
 } dp_conv_params;
 int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
 /* which kernel dp_conv2d_nhwc will launch for these parameters: 0 = generic 128x64 tile, 1 = generic 128x128 tile, 2 = 256x256 LDS-ring tile,
@@ -178,7 +185,11 @@ int dp_conv2d_nhwc(const dp_conv_params* p, dp_stream_t stream);
  * instead of handing it to another class), 9 = weight-stationary pointwise kernel (1 tap, stride 1, K = 512 / 1024 / 2048 channels:
  * conv1 of res4 / res5 and conv3 of res5 resnet.py:189-205, the FPN laterals fpn.py:140-157, fc2 box_head.py:71-73; a 256 KiB slice
  * of the weights in registers, pixels once through LDS, K slices added in a fixed order of its own - chosen by the channel counts
- * alone) - profiling / roofline bookkeeping only */
+ * alone), 10 = weight-stationary 3x3 kernel with ONE wave per SIMD (256 -> 256 channels: res4 conv2 resnet.py:195-197, the FPN output
+ * convolutions fpn.py:134-157, the DensePose decoder's scale heads roi_head.py:48-68; 32 couts x 1152 K of the weights in each wave's 512
+ * registers, four output rows of a 16-pixel strip per step, every bit of step bookkeeping in the MFMAs' shadow; policy key wsq_shape picks
+ * the v_mfma_f32_16x16x32 form (default) or the 32x32x16 form; a summation order of its own - chosen by the per-image geometry and the
+ * channel counts alone, never by N; honours post_res; a launch with ring_order = 1 is never given to it) - profiling / roofline bookkeeping only */
 int dp_conv2d_kernel_class(const dp_conv_params* p);
 /* pixel rows of the tile dp_conv2d_nhwc will use for these parameters (the 256-cout ring kernel picks 128 .. 256 rows in
  * steps of 32 to fit the launch into whole rounds of the chip) - profiling / roofline bookkeeping only */

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in _declared_symbols():
         assert hasattr(raw, name), name
     lib = built.load()
-    assert lib.dp_abi_version() == 7 == built.ABI_VERSION
+    assert lib.dp_abi_version() == 8 == built.ABI_VERSION
 
 
 def test_argument_validation_without_gpu(built):

@@ -205,7 +205,8 @@ def test_full_width_network_runs_on_the_documented_kernel_classes():
         assert all(c.startswith(("conv1x1_pws_kernel", "conv1x1_pwq_kernel")) for c in cls_of(lname)), (lname, cls_of(lname))
     assert all(c == "bottleneck_pair128_kernel" for c in cls_of("res3.1.conv3")), cls_of("res3.1.conv3")
     assert all(c == "bottleneck_tail64_kernel" for c in cls_of("res2.1.conv2")), cls_of("res2.1.conv2")
-    assert all(c.startswith(("conv3x3_wsr", "conv3x3_rows")) for c in cls_of("res4.2.conv2")), cls_of("res4.2.conv2")
+    assert all(c.startswith("conv3x3_wsq") for c in cls_of("res4.2.conv2")), cls_of("res4.2.conv2")      # kernel class 10 (dp_conv_wq.hip)
+    assert all(c.startswith("conv3x3_wsr_kernel<128") for c in cls_of("res3.1.conv2")), cls_of("res3.1.conv2")
     dec = cls_of("dp_predictor")      # one grouped launch where the LDS-ring kernels take the shape, else the four launches
     assert (len(dec) == 1 and dec[0].endswith(",x4>")) or len(dec) == 4, dec
 

@@ -192,7 +192,8 @@ def test_conv2d_stream_kernel(eng, dt, case, policy):
 
 def test_split_k_is_a_hint_and_n_dev_launches_skip_dead_images(eng):
     """dp_conv_params.split_k on a layer the split instances do not take (a residual here) runs UNSPLIT, same bits, no error; and an n_dev
-    launch of a 256 -> 256 3x3 (the weight-stationary kernel's shape) runs on a tiled kernel and leaves the slots behind the live count alone."""
+    launch of a 256 -> 256 3x3 runs on the kernel the layer always runs on (class 10 sizes its work from the live count: the choice of a
+    kernel with a summation order of its own must not depend on whether a count is passed) and leaves the slots behind the live count alone."""
     from densepose_torchscript_amd import lib as L
     from densepose_torchscript_amd.engine import Act
     from densepose_torchscript_amd.pack import conv_from_oihw, set_split_k
@@ -224,13 +225,21 @@ def test_split_k_is_a_hint_and_n_dev_launches_skip_dead_images(eng):
     layer.split_k = 0
     n_dev = torch.tensor([2], dtype=torch.int32, device=e.device)
     p.residual, p.split_k, p.split_ws, p.n_dev = None, 0, None, n_dev.data_ptr()
-    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) in (0, 1, 2, 3, 4)
+    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 10
     out3 = torch.full((N, H, W, Co), 7.0, dtype=e.tdt, device=e.device)
     got3 = e.conv(layer, x, relu=True, out=out3, n_dev=n_dev)
     torch.cuda.synchronize()
-    assert bool((got3.t[3:].float() == 7.0).all())      # (the image right behind the count may share the last live tile)
+    assert bool((got3.t[2:].float() == 7.0).all())
     plain = e.conv(layer, x, relu=True)
     assert torch.equal(got3.t[:2], plain.t[:2])
+    with L.policy(conv_wsq=0):       # ... and the tiled kernels behind it (the persistent class 6 ignores the count and is never given one)
+        assert e.lib.dp_conv2d_kernel_class(C.byref(p)) in (0, 1, 2, 3, 4)
+        out4 = torch.full((N, H, W, Co), 7.0, dtype=e.tdt, device=e.device)
+        got4 = e.conv(layer, x, relu=True, out=out4, n_dev=n_dev)
+        plain4 = e.conv(layer, x, relu=True)
+        torch.cuda.synchronize()
+        assert bool((got4.t[3:].float() == 7.0).all())      # (the image right behind the count may share the last live tile)
+        assert torch.equal(got4.t[:2], plain4.t[:2])
 
 
 PWS_CASES = [
@@ -699,6 +708,7 @@ def test_conv3x3_weight_stationary_equals_ring_kernel(eng, dt, shape, policy):
     e = eng[dt]
     Cc, N, H, W, relu = shape
     policy.default("conv_ws")
+    policy.set("conv_wsq", "0")      # (the 256-channel layers run on kernel class 10 by default: test_conv3x3_one_wave_per_simd_kernel below)
     g = torch.Generator().manual_seed(N * 1000 + H * 10 + W + Cc)
     x = _round(torch.randn((N, Cc, H, W), generator=g), dt)
     w = _round(torch.randn((Cc, Cc, 3, 3), generator=g) * (1.0 / (9 * Cc)) ** 0.5, dt)
@@ -731,6 +741,92 @@ def test_conv3x3_weight_stationary_equals_ring_kernel(eng, dt, shape, policy):
     ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
     gd = got.t.float().cpu().permute(0, 3, 1, 2).double()
     assert bool(((gd - ref).abs() <= ulp * ref.abs() + 2e-3).all()), float((gd - ref).abs().max())
+
+
+WSQ_CASES = [(1, 13, 21, True), (2, 9, 17, False), (3, 37, 45, True), (1, 8, 16, True), (2, 25, 42, True), (1, 50, 84, True), (2, 64, 35, False),
+             (1, 47, 130, True), (8, 13, 32, True), (1, 4, 40, True), (2, 3, 50, True), (1, 1, 130, False), (6, 16, 25, True), (2, 100, 168, False)]
+
+
+@pytest.mark.parametrize("mfma", [16, 32])
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", WSQ_CASES)
+def test_conv3x3_one_wave_per_simd_kernel(eng, dt, case, mfma, policy):
+    """Kernel class 10 (dp_conv_wq.hip): the 256 -> 256 3x3 layers (res4 conv2 resnet.py:195-197, FPN outputs fpn.py:134-157, the decoder's
+    scale heads roi_head.py:48-68) with ONE wave per SIMD - conv3x3_ws1_kernel on v_mfma_f32_16x16x32 (default) and conv3x3_wsq_kernel on
+    v_mfma_f32_32x32x16 (policy key wsq_shape). Against torch in fp64 on operands rounded to the storage type, against kernel class 6
+    within two rounding steps (another summation order: K halves of two waves added through LDS), every image alone == in the batch
+    bit for bit, the scheduling hints (other splits of the steps over workgroups) bit for bit, and the class is a function of the
+    per-image geometry alone: the same for N = 1 and N = 64, not taken when the caller pins the ring family's order (ring_order)."""
+    from densepose_torchscript_amd import lib as L
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    e = eng[dt]
+    N, H, W, relu = case
+    Cc = 256
+    policy.set("wsq_shape", str(mfma))
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W + mfma)
+    x = _round(torch.randn((N, Cc, H, W), generator=g), dt)
+    w = _round(torch.randn((Cc, Cc, 3, 3), generator=g) * (1.0 / (9 * Cc)) ** 0.5, dt)
+    b = torch.randn((Cc,), generator=g) * 0.3
+    layer = conv_from_oihw("conv2", w.numpy(), b.numpy(), Cc, 1, 1, 1, e.dt, e.device)
+    xa = Act(_nhwc(x, Cc, e.tdt, e.device), N, H, W, Cc)
+    p = L.ConvParams()
+    p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = H, W, Cc, H, W, Cc, Cc, 9 * Cc
+    p.stride, p.ntaps, p.dtype, p.hi_off, p.wi_off = 1, 9, e.dt, -1, -1
+    p.osN, p.osH, p.osW = H * W * Cc, W * Cc, Cc
+    p.out = 4096
+    want_cls = 10 if H * W >= 128 else None
+    for n in (1, N, 64):
+        p.N = n
+        for hint in (0, 1, 2):
+            p.shared_chip = hint
+            k = e.lib.dp_conv2d_kernel_class(C.byref(p))
+            assert (k == 10) == (want_cls == 10), (n, hint, k)
+    p.shared_chip, p.ring_order = 0, 1
+    assert e.lib.dp_conv2d_kernel_class(C.byref(p)) != 10
+    if want_cls is None:
+        return
+    got = e.conv(layer, xa, relu=relu)
+    for hint in (1, 2):
+        e._shared_chip = hint
+        try:
+            assert torch.equal(got.t, e.conv(layer, xa, relu=relu).t), hint
+        finally:
+            e._shared_chip = False
+    for i in range(N):
+        one = e.conv(layer, Act(xa.t[i:i + 1].contiguous(), 1, H, W, Cc), relu=relu)
+        assert torch.equal(one.t[0], got.t[i]), i
+    pinned = e.conv(layer, xa, relu=relu, ring_order=True)
+    policy.set("conv_wsq", "0")
+    older = e.conv(layer, xa, relu=relu)
+    torch.cuda.synchronize()
+    assert torch.equal(pinned.t, older.t)          # ring_order = the bits of classes 2 - 6
+    ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    d = (got.t.float() - older.t.float()).abs()
+    assert bool((d <= 2 * ulp * older.t.float().abs() + 1e-3).all()), float(d.max())
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = F.relu(ref) if relu else ref
+    gd = got.t.float().cpu().permute(0, 3, 1, 2).double()
+    assert bool(((gd - ref).abs() <= ulp * ref.abs() + 2e-3).all()), float((gd - ref).abs().max())
+
+
+def test_conv3x3_one_wave_per_simd_kernel_chunks_large_batches(eng, policy):
+    """A batch whose tensors pass the 32-bit offset range is cut into image chunks INSIDE the launch function (the class never depends on N):
+    with the chunk limit lowered to three images the bits are those of the unchunked launch."""
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    e = eng["bf16"]
+    N, H, W, Cc = 7, 20, 30, 256
+    g = torch.Generator().manual_seed(77)
+    x = _round(torch.randn((N, Cc, H, W), generator=g), "bf16")
+    w = _round(torch.randn((Cc, Cc, 3, 3), generator=g) * (1.0 / (9 * Cc)) ** 0.5, "bf16")
+    layer = conv_from_oihw("c", w.numpy(), np.zeros(Cc, np.float32), Cc, 1, 1, 1, e.dt, e.device)
+    xa = Act(_nhwc(x, Cc, e.tdt, e.device), N, H, W, Cc)
+    whole = e.conv(layer, xa, relu=True).t.clone()
+    policy.set("rows_chunk_bytes", str(3 * H * W * Cc * 2))
+    parts = e.conv(layer, xa, relu=True).t
+    torch.cuda.synchronize()
+    assert torch.equal(whole, parts)
 
 
 ROWS_CASES = [
@@ -863,10 +959,11 @@ def test_conv3x3_rows_kernel(eng, dt, case, variant, policy):
     assert bool((d <= 2 * ulp * want.t[:nl].float().abs() + 1e-3).all()), float(d.max())
 
 
+@pytest.mark.parametrize("kernel", ["ws1", "wsq32", "wsr"])     # kernel class 10 in its two MFMA shapes, kernel class 6
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("shape", [(1, 50, 84), (2, 24, 46), (3, 30, 26), (1, 100, 168), (8, 14, 22)])
-def test_conv3x3_post_activation_sum(eng, dt, mode, shape):
+def test_conv3x3_post_activation_sum(eng, dt, mode, shape, kernel, policy):
     """dp_conv_params.post_res (the decoder's level sum in the conv epilogue, roi_head.py:71-79): out = relu(conv(x) + b) + post
     (mode 1, same geometry) and out = relu(conv(x) + b) + bilinear_x2(post) (mode 2, half-size map, align_corners=False) on the
     weight-stationary 3x3 kernel, against torch in fp64 - ragged heights / strip widths, several images, more workgroups than
@@ -876,6 +973,12 @@ def test_conv3x3_post_activation_sum(eng, dt, mode, shape):
     e = eng[dt]
     N, H, W = shape
     Cc = 256
+    if kernel == "wsr":
+        if N * H * W < 2048:
+            pytest.skip("class 6 takes a post tensor from 2048 output pixels per launch on")
+        policy.set("conv_wsq", "0")
+    else:
+        policy.set("wsq_shape", "32" if kernel == "wsq32" else "16")
     g = torch.Generator().manual_seed(1000 * mode + H * W + N)
     x = _round(torch.randn((N, Cc, H, W), generator=g), dt)
     w = _round(torch.randn((Cc, Cc, 3, 3), generator=g) * (2.0 / (Cc * 9)) ** 0.5, dt)
@@ -887,6 +990,14 @@ def test_conv3x3_post_activation_sum(eng, dt, mode, shape):
     pa = Act(_nhwc(post, Cc, e.tdt, e.device), N, hp, wp, Cc)
     assert e.post_fusable(layer, xa, mode)
     got = e.conv(layer, xa, relu=True, post=pa, post_mode=mode)
+    hinted = []
+    for hint in (1, 2):      # the host's scheduling hints move work between workgroups, never bits
+        e._shared_chip = hint
+        try:
+            hinted.append(e.conv(layer, xa, relu=True, post=pa, post_mode=mode))
+        finally:
+            e._shared_chip = False
+    assert all(torch.equal(got.t, h.t) for h in hinted)
     plain = e.conv(layer, xa, relu=True)
     torch.cuda.synchronize()
     ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))
@@ -1578,6 +1689,7 @@ def test_conv3x3_wsr_small_maps_equal_the_ring_kernel(eng, dt, C_, policy):
     w = _round(torch.randn((C_, C_, 3, 3), generator=g) * (1.0 / (9 * C_)) ** 0.5, dt)
     b = torch.randn((C_,), generator=g) * 0.1
     layer = conv_from_oihw("l", w.numpy(), b.numpy(), C_, 1, 1, 1, e.dt, e.device)
+    policy.set("conv_wsq", "0")      # (kernel class 10 takes the 256-channel layers by default; this test is about class 6)
     for (N, H, W) in [(3, 8, 13), (1, 13, 21), (1, 25, 42), (2, 7, 9), (1, 6, 16), (2, 9, 17), (1, 12, 33)]:
         x = Act(_nhwc(_round(torch.randn((N, C_, H, W), generator=g), dt), C_, e.tdt, e.device), N, H, W, C_)
         p = L.ConvParams()

@@ -40,8 +40,12 @@ def klass(x):
     return e.lib.dp_conv2d_kernel_class(C.byref(p))
 
 
+INPUT = os.environ.get("INPUT", "randn")   # randn | relu (half of the values zero, like a layer behind a ReLU) | zero
+
+
 def act(n, h, wd):
-    x = torch.randn((n, h, wd, Cc), generator=g).to(tdt)
+    x = torch.randn((n, h, wd, Cc), generator=g)
+    x = (torch.relu(x) if INPUT == "relu" else x * 0 if INPUT == "zero" else x).to(tdt)
     return Act(x.cuda(), n, h, wd, Cc), x
 
 
@@ -78,6 +82,26 @@ if os.environ.get("CHECK", "1") != "0":
         nz = float((d > 0).float().mean())
         print("check N=%d %dx%d against class %d: max |diff| %.3e, %.4f of the elements differ  %s" % (n, h, wd, 6, float(d.max()), nz, "ok" if ok else "WRONG"))
         bad += not ok
+    # the host's scheduling hints change the split of the steps over workgroups, never the bits
+    for shp in (16, 32):
+        L.set_policy("wsq_shape", shp)
+        for (n, h, wd) in [(6, 64, 100), (6, 32, 50), (6, 16, 25), (1, 16, 25), (2, 50, 84), (8, 25, 42), (3, 100, 168), (1, 64, 100)]:
+            xa, x = act(n, h, wd)
+            outs = []
+            for hint in (0, 1, 2):
+                e._shared_chip = hint
+                outs.append(e.conv(layer, xa, relu=True).t.clone())
+            e._shared_chip = 0
+            one = torch.cat([e.conv(layer, Act(xa.t[i:i + 1].contiguous(), 1, h, wd, Cc), relu=True).t for i in range(n)])
+            torch.cuda.synchronize()
+            res = [torch.equal(outs[0], outs[1]), torch.equal(outs[0], outs[2]), torch.equal(outs[0], one)]
+            if not all(res):
+                d = (outs[0].float() - outs[1].float()).abs() + (outs[0].float() - outs[2].float()).abs() + (outs[0].float() - one.float()).abs()
+                idx = torch.nonzero(d.sum(-1) > 0)
+                print("  differing pixels (n, y, x):", idx[:12].tolist(), "count", idx.shape[0], "channels of the first:", torch.nonzero(d[tuple(idx[0])] > 0).flatten()[:8].tolist())
+            print("hints shape=%d N=%d %dx%d: hint1 == hint0 %s, hint2 == hint0 %s, single == batch %s" % (shp, n, h, wd, *res))
+            bad += not all(res)
+    L.set_policy("wsq_shape", 16)
     print("CHECK", "PASSED" if bad == 0 else "FAILED (%d)" % bad)
 
 
@@ -110,9 +134,9 @@ for (h, wd) in shapes:
     out = torch.empty((N, h, wd, Cc), dtype=tdt, device="cuda")
     fl = 2.0 * N * h * wd * Cc * Cc * 9
     res = []
-    for name, pol in (("wsq (class 10)", {"conv_wsq": 1}), ("wsr (class 6)", {"conv_wsq": 0}), ("ring", {"conv_wsq": 0, "conv_ws": 0})):
+    for name, pol in (("ws1 16x16x32", {"conv_wsq": 1, "wsq_shape": 16}), ("wsq 32x32x16", {"conv_wsq": 1, "wsq_shape": 32}), ("wsr", {"conv_wsq": 0}), ("ring", {"conv_wsq": 0, "conv_ws": 0})):
         with L.policy(**pol):
             k = klass(xa)
             ms = bench(xa, out)
-        res.append("%s: class %d %.4f ms %.0f TFLOP/s (%.3f)" % (name, k, ms, fl / ms / 1e9, fl / ms / 1e9 / 2500))
-    print("N=%d %dx%d  " % (N, h, wd) + " | ".join(res))
+        res.append("%s: %d %.4f ms %.0f TF (%.3f)" % (name, k, ms, fl / ms / 1e9, fl / ms / 1e9 / 2500))
+    print("N=%d %dx%d input=%s  " % (N, h, wd, INPUT) + " | ".join(res))
