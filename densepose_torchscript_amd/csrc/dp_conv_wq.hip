@@ -45,7 +45,7 @@
 #define DP_WSQ_ROWS_VIA_REGS 0   // steady-state row fetches: buffer_load into registers + ds_write_b128 later in the step (0: LDS-DMA)
 #endif
 #ifndef DP_WSQ_DMA_GAP
-#define DP_WSQ_DMA_GAP 7  // fragments between two LDS-DMA pieces of a wave
+#define DP_WSQ_DMA_GAP 2  // fragments between two LDS-DMA pieces of a wave (2 / 4 / 7 measure the same; every piece must be OLDER than the step's stores: see the vmcnt at its end)
 #endif
 
 namespace {
@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wsq_kernel(const WsqArgs p) {
   unsigned nrb = row_base(st_n, 2 + wave, nst > 1), nrb_n = 0;
   bool n_first = nst > 1 && st_n.first;
   constexpr int NF = 96, AHEAD = DP_WSQ_AHEAD, DMA_GAP = DP_WSQ_ROWS_VIA_REGS ? 4 : DP_WSQ_DMA_GAP, ST0 = 40;
+  static_assert(DP_WSQ_ROWS_VIA_REGS || 2 + DMA_GAP * (kWqPPR - 1) < 24, "the last LDS-DMA piece of a step is issued before its first store / exchange read: vmcnt(stores + post loads) then covers every piece");
   u32x4 rowbuf[PPR];
 
   for (int i = 0; i < nst; ++i) {
@@ -604,10 +605,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws1_kernel(const WsqArgs p) {
   int e_off = 0, e_rows = 0;
 #pragma unroll
   for (int t = 0; t < 4; ++t) eacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // post tensor values of the pending step. POST = 1: the lane's 4 channels at its pixel of each row. POST = 2: the four half-size
-  // neighbours of its pixel of each row (two source rows, wave-uniform, x two source columns) + the weights.
-  constexpr int NPV = POST == 1 ? 4 : (POST == 2 ? 16 : 1);
-  constexpr int NPL = POST == 1 ? 4 : (POST == 2 ? 16 : 0);
+  // post tensor values of the pending step. POST = 1: the lane's 4 channels at its pixel of each row. POST = 2: the FOUR half-size rows
+  // b' .. b' + 3, b' = r / 2 - 1 (clamped to the map), at the lane's two source columns. A step's first output row r is a multiple of 4,
+  // so output row r + t always interpolates between the rows (0, 1), (1, 2), (1, 2), (2, 3) of those four (ATen's align_corners = False
+  // source index: (o + 0.5) / 2 - 0.5, clamped at 0; at r = 0 the clamped row -1 IS row 0 and its weight is ly = 0 or the same row's).
+  constexpr int NPV = POST == 1 ? 4 : (POST == 2 ? 8 : 1);
+  constexpr int NPL = POST == 1 ? 4 : (POST == 2 ? 8 : 0);
   u32x2w pv[NPV];
 #pragma unroll
   for (int k = 0; k < NPV; ++k) pv[k] = u32x2w{0u, 0u};
@@ -622,19 +625,36 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws1_kernel(const WsqArgs p) {
     } else if constexpr (POST == 2) {
       int x0, x1;
       wq_bil_src(min(col, p.W - 1), p.Wl, x0, x1, p_lx);
+      const int bq = (st.r >> 1) - 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = min(max(bq + k, 0), p.Hl - 1);
+        const int off = ((st.n * p.Hl + row) * p.Wl) * opix + ocb;
+        pv[2 * k] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, off + x0 * opix, 0, 0);
+        pv[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, off + x1 * opix, 0, 0);
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         int y0, y1;
-        wq_bil_src(min(st.r + t, p.H - 1), p.Hl, y0, y1, p_ly[t]);       // wave-uniform
-        const int o0 = ((st.n * p.Hl + y0) * p.Wl) * opix + ocb, o1 = ((st.n * p.Hl + y1) * p.Wl) * opix + ocb;
-        pv[4 * t + 0] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, o0 + x0 * opix, 0, 0);
-        pv[4 * t + 1] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, o0 + x1 * opix, 0, 0);
-        pv[4 * t + 2] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, o1 + x0 * opix, 0, 0);
-        pv[4 * t + 3] = __builtin_amdgcn_raw_buffer_load_b64(rs_post, o1 + x1 * opix, 0, 0);
+        wq_bil_src(st.r + t, p.Hl, y0, y1, p_ly[t]);       // wave-uniform; only the weight is used
       }
     }
   };
-  auto epi_prepare = [&]() __attribute__((always_inline)) {};
+  // POST = 2: the horizontal half of the interpolation once per half-size row
+  float hrow[POST == 2 ? 4 : 1][4];
+  auto epi_prepare = [&]() __attribute__((always_inline)) {
+    if constexpr (POST == 2) {
+      const float hx = 1.f - p_lx;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int sh = (e & 1) * 16;
+          const float fa = Elem<T>::unpack((pv[2 * k][e >> 1] >> sh) & 0xffffu), fb = Elem<T>::unpack((pv[2 * k + 1][e >> 1] >> sh) & 0xffffu);
+          hrow[k][e] = hx * fa + p_lx * fb;
+        }
+    }
+  };
   f32x4 eo[4];
   auto epi_read = [&](int par, auto tt) __attribute__((always_inline)) {
     constexpr int t = decltype(tt)::value;
@@ -655,14 +675,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws1_kernel(const WsqArgs p) {
         v[2 * e + 1] += Elem<T>::unpack(pv[t][e] >> 16);
       }
     } else if constexpr (POST == 2) {
-      const float hx = 1.f - p_lx, hy = 1.f - p_ly[t];
+      constexpr int i = t == 0 ? 0 : (t == 3 ? 2 : 1), j = i + 1;     // rows of hrow this output row interpolates between
+      const float hy = 1.f - p_ly[t];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int sh = (e & 1) * 16;
-        const float a = Elem<T>::unpack((pv[4 * t + 0][e >> 1] >> sh) & 0xffffu), bb = Elem<T>::unpack((pv[4 * t + 1][e >> 1] >> sh) & 0xffffu);
-        const float c = Elem<T>::unpack((pv[4 * t + 2][e >> 1] >> sh) & 0xffffu), d = Elem<T>::unpack((pv[4 * t + 3][e >> 1] >> sh) & 0xffffu);
-        v[e] += hy * (hx * a + p_lx * bb) + p_ly[t] * (hx * c + p_lx * d);     // ATen's order
-      }
+      for (int e = 0; e < 4; ++e) v[e] += hy * hrow[i][e] + p_ly[t] * hrow[j][e];      // ATen's order: hy * (hx * a + lx * b) + ly * (hx * c + lx * d)
     }
     const u32x2w pk = {Elem<T>::pack2(v[0], v[1]), Elem<T>::pack2(v[2], v[3])};
     __builtin_amdgcn_raw_buffer_store_b64(pk, rs_out, t < e_rows ? e_off + t * (p.W * opix) : (int)kLaneInv, 0, 0);
@@ -684,6 +700,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws1_kernel(const WsqArgs p) {
   unsigned nrb = row_base(st_n, 2 + wave, nst > 1), nrb_n = 0;
   bool n_first = nst > 1 && st_n.first;
   constexpr int NF = 72, AHEAD = DP_WSQ_AHEAD, DMA_GAP = 3;
+  static_assert(1 + DMA_GAP * (kWqPPR - 1) < 32, "the last LDS-DMA piece of a step is issued before its first store: vmcnt(stores + post loads) then covers every piece");
   // fragment f = (channel block cbl of 32, position in the row order, column tap dx)
   constexpr int kRowOrder[6] = {2, 0, 3, 5, 1, 4};
 
@@ -765,7 +782,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws1_kernel(const WsqArgs p) {
     DP_STAMP(2)
     // the rows fetched in this iteration have landed: every fetch is older than this iteration's four stores (and post loads)
     if constexpr (NPL == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (NPL == 16) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (NPL == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     DP_STAMP(3)
