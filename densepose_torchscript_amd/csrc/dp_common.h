@@ -136,6 +136,9 @@ int dp_conv_rows_launch(const dp_conv_params* p, dp_stream_t stream);
 bool dp_conv_pws_ok(const dp_conv_params* p);
 int dp_conv_pws_launch(const dp_conv_params* p, dp_stream_t stream);
 
+// dp_pair256.hip: the res4 form (256 -> 1024 -> 256) of dp_bottleneck_pair_nhwc
+int dp_pair256_launch(const dp_pair_params* p, dp_stream_t stream);
+
 // Packed weight matrices are stored in 1 KiB TILES of 16 rows x 64 bytes of K (round 3): tile (rg, plane) of a matrix with
 // n_planes = Kpad * esize / 64 K planes sits at ((rg * n_planes) + plane) * 1024, row-major inside. One LDS-DMA wave instruction (16
 // rows of one plane, what every convolution kernel stages) then reads 8 consecutive whole cache lines instead of 16 half lines from

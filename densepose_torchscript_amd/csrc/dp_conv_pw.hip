@@ -711,7 +711,6 @@ bool dp_conv_pws_ok(const dp_conv_params* p) {
   const int sk = p->Cin == 512 ? 1 : (p->Cin == 1024 ? 2 : (p->Cin == 2048 ? 4 : 0));
   if (sk == 0 && p->Cin != 256) return false;
   const int cw = p->Cin == 256 ? 512 : 256 / sk;      // 256 channels: the 64-couts-per-wave form (conv1x1_pwq_kernel)
-  const long long M = (long long)p->N * p->Ho * p->Wo;
   const bool lin_out = p->osW == p->Cout && p->osH == (long long)p->Wo * p->osW && p->osN == (long long)p->Ho * p->osH;
   const bool lin_res = !p->residual || (p->rshift == 0 && p->rsW == p->Cout && p->rsH == (long long)p->Wo * p->rsW && p->rsN == (long long)p->Ho * p->rsH);
   const bool up_res = p->residual && p->rshift == 1 && p->Ho % 2 == 0 && p->Wo % 2 == 0 && p->rsW == p->Cout && p->rsH == (long long)(p->Wo / 2) * p->rsW &&
@@ -719,29 +718,45 @@ bool dp_conv_pws_ok(const dp_conv_params* p) {
   return p->ntaps == 1 && p->stride == 1 && (p->stride_w == 0 || p->stride_w == 1) && p->hi_off == 0 && p->wi_off == 0 && p->H == p->Ho && p->W == p->Wo &&
          p->Kpad == p->Cin && p->Cout % cw == 0 && p->Cout <= p->Cout_w && !p->n_dev && !p->in2 && !p->head_out && !p->post_res && p->post_mode == 0 &&
          p->split_k <= 1 && !p->out_f32 && p->out && lin_out && (lin_res || up_res) &&
-         (M + 64) * p->Cin * 2 < (1ll << 31) && (M + 64) * p->Cout * 2 < (1ll << 31) &&
+         // (one image inside the 32-bit offset range; a BATCH beyond it is cut into image chunks by dp_conv_pws_launch - the class never depends on N)
+         ((long long)p->Ho * p->Wo + 64) * p->Cin * 2 < (1ll << 31) && ((long long)p->Ho * p->Wo + 64) * p->Cout * 2 < (1ll << 31) &&
          (((uintptr_t)p->in | (uintptr_t)p->out | (uintptr_t)p->weight | (uintptr_t)p->residual) & 15) == 0;
 }
 
 int dp_conv_pws_launch(const dp_conv_params* p, dp_stream_t stream) {
-  PwsArgs a;
-  a.in = p->in; a.w = p->weight; a.bias = p->bias; a.res = p->residual; a.out = p->out;
-  a.M = p->N * p->Ho * p->Wo; a.cout = p->Cout; a.relu = p->relu; a.kpad = p->Kpad;
-  a.n_slices = a.n_pg = a.S = 0;
-  a.dbg = nullptr;
-  a.in_bytes = (unsigned)((long long)a.M * p->Cin * 2);
-  a.out_bytes = (unsigned)((long long)a.M * p->Cout * 2);
-  a.res_up = p->residual && p->rshift == 1;
-  a.res_bytes = p->residual ? (unsigned)((long long)p->N * p->rsN * 2) : 0u;
-  a.HoWo = p->Ho * p->Wo; a.Wo = p->Wo;
-  a.rsN = (int)p->rsN; a.rsH = (int)p->rsH; a.rsW = (int)p->rsW;
+  // 32-bit buffer offsets: a batch whose tensors pass the range goes image chunk by image chunk (pixels are independent; the per-pixel
+  // arithmetic does not know about the chunking). rows_chunk_bytes: the limit, lowered by tests.
+  const long long hw = (long long)p->Ho * p->Wo;
+  const long long per_img = (hw + 64) * (p->Cin > p->Cout ? p->Cin : p->Cout) * 2;
+  const long long lim = dp_policy().rows_chunk_bytes < (1ll << 31) - 1 ? dp_policy().rows_chunk_bytes : (1ll << 31) - 1;
+  int per = (int)(lim / per_img);
+  if (per < 1) per = 1;
   hipStream_t s = as_stream(stream);
   const bool bf = p->dtype == DP_BF16;
-  if (p->Cin == 256) {
-    if (a.res) return bf ? launch_pwq_r<uint16_t, true>(a, s) : launch_pwq_r<f16_t, true>(a, s);
-    return bf ? launch_pwq_r<uint16_t, false>(a, s) : launch_pwq_r<f16_t, false>(a, s);
+  for (int n0 = 0; n0 < p->N; n0 += per) {
+    const int n = p->N - n0 < per ? p->N - n0 : per;
+    PwsArgs a;
+    a.in = reinterpret_cast<const unsigned char*>(p->in) + (long long)n0 * hw * p->Cin * 2;
+    a.w = p->weight; a.bias = p->bias;
+    a.res = p->residual ? reinterpret_cast<const unsigned char*>(p->residual) + (long long)n0 * p->rsN * 2 : nullptr;
+    a.out = reinterpret_cast<unsigned char*>(p->out) + (long long)n0 * hw * p->Cout * 2;
+    a.M = (int)(n * hw); a.cout = p->Cout; a.relu = p->relu; a.kpad = p->Kpad;
+    a.n_slices = a.n_pg = a.S = 0;
+    a.dbg = nullptr;
+    a.in_bytes = (unsigned)((long long)a.M * p->Cin * 2);
+    a.out_bytes = (unsigned)((long long)a.M * p->Cout * 2);
+    a.res_up = p->residual && p->rshift == 1;
+    a.res_bytes = p->residual ? (unsigned)((long long)n * p->rsN * 2) : 0u;
+    a.HoWo = p->Ho * p->Wo; a.Wo = p->Wo;
+    a.rsN = (int)p->rsN; a.rsH = (int)p->rsH; a.rsW = (int)p->rsW;
+    int rc;
+    if (p->Cin == 256) {
+      if (a.res) rc = bf ? launch_pwq_r<uint16_t, true>(a, s) : launch_pwq_r<f16_t, true>(a, s);
+      else rc = bf ? launch_pwq_r<uint16_t, false>(a, s) : launch_pwq_r<f16_t, false>(a, s);
+    } else if (p->Cin == 512) rc = bf ? launch_pws<uint16_t, 1>(a, s) : launch_pws<f16_t, 1>(a, s);
+    else if (p->Cin == 1024) rc = bf ? launch_pws<uint16_t, 2>(a, s) : launch_pws<f16_t, 2>(a, s);
+    else rc = bf ? launch_pws<uint16_t, 4>(a, s) : launch_pws<f16_t, 4>(a, s);
+    if (rc != DP_OK) return rc;
   }
-  if (p->Cin == 512) return bf ? launch_pws<uint16_t, 1>(a, s) : launch_pws<f16_t, 1>(a, s);
-  if (p->Cin == 1024) return bf ? launch_pws<uint16_t, 2>(a, s) : launch_pws<f16_t, 2>(a, s);
-  return bf ? launch_pws<uint16_t, 4>(a, s) : launch_pws<f16_t, 4>(a, s);
+  return DP_OK;
 }

@@ -25,6 +25,7 @@
 //     sums instead of one 512-channel chain: its own summation order, which is why a call site runs here for every batch size or never.
 #include "dp_common.h"
 #include "dp_mma.h"
+#include "dp_policy.h"
 
 namespace {
 
@@ -262,9 +263,11 @@ int launch_pair(PairArgs a, hipStream_t stream) {
 
 const char* pair_unsupported(const dp_pair_params* p) {
   if (!(p->dtype == DP_BF16 || p->dtype == DP_F16)) return "16-bit storage only (fp32 parity mode runs the two layers one by one)";
-  if (p->Cmid != 128 || p->Cout != 512 || p->Cmid_next != 128) return "channel counts 128 -> 512 -> 128 only (the plain blocks of res3)";
-  if (p->Kpad3 != 128 || p->Kpad1n != 512) return "packed K lengths 128 / 512 expected";
-  if (p->M < 0 || (p->M + 64) * 1024 >= (1ll << 31)) return "tensor too large for 32-bit buffer offsets (caller chunks the batch)";
+  const bool r3 = p->Cmid == 128 && p->Cout == 512 && p->Cmid_next == 128, r4 = p->Cmid == 256 && p->Cout == 1024 && p->Cmid_next == 256;
+  if (!r3 && !r4) return "channel counts 128 -> 512 -> 128 (the plain blocks of res3) or 256 -> 1024 -> 256 (res4) only";
+  if (r4 && dp_policy().pair256 == 0) return "the res4 form is off by default (policy key pair256): slower than the two launches, profiles/r6_pair256_experiments.txt";
+  if (p->Kpad3 != p->Cmid || p->Kpad1n != p->Cout) return "packed K lengths = the channel counts expected";
+  if (p->M < 0 || (p->M + 64) * p->Cout * 2 >= (1ll << 31)) return "tensor too large for 32-bit buffer offsets (caller chunks the batch)";
   return nullptr;
 }
 
@@ -283,6 +286,7 @@ extern "C" int dp_bottleneck_pair_nhwc(const dp_pair_params* p, dp_stream_t stre
   DP_REQUIRE(p->t2 && p->residual && p->out && p->next_t1 && p->w3 && p->w1n && p->b3 && p->b1n, "dp_bottleneck_pair_nhwc: null pointer");
   DP_REQUIRE((((uintptr_t)p->t2 | (uintptr_t)p->residual | (uintptr_t)p->out | (uintptr_t)p->next_t1 | (uintptr_t)p->w3 | (uintptr_t)p->w1n) & 15) == 0,
              "dp_bottleneck_pair_nhwc: tensors must be 16-byte aligned");
+  if (p->Cmid == 256) return dp_pair256_launch(p, stream);      // res4: both matrices streamed through LDS (dp_pair256.hip)
   PairArgs a;
   a.t2 = p->t2; a.res = p->residual; a.out = p->out; a.t1n = p->next_t1;
   a.w3 = p->w3; a.w1 = p->w1n; a.b3 = p->b3; a.b1 = p->b1n;

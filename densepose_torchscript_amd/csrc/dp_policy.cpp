@@ -33,6 +33,7 @@ const Key kKeys[] = {
     {"rows_chunk_bytes", &DpPolicy::rows_chunk_bytes},
     {"conv_pws", &DpPolicy::conv_pws},
     {"pws_skew", &DpPolicy::pws_skew},
+    {"pair256", &DpPolicy::pair256},
     {"tail_kernel", &DpPolicy::tail_kernel},
     {"roi_tab", &DpPolicy::roi_tab},
     {"iuv_quad", &DpPolicy::iuv_quad},

@@ -32,6 +32,9 @@ struct DpPolicy {
   // weight-stationary pointwise (dp_conv_pw.hip)
   int64_t conv_pws = 1;             // 0 = never chosen
   int64_t pws_skew = 0;             // (DP_EXPERIMENTS builds only) 1 = the halves of the workgroup half a step apart, two barriers per step
+  // res4's conv3 -> next-conv1 pair kernel (dp_pair256.hip): built, verified, measured SLOWER than the two launches at the benchmark geometry
+  // (profiles/r6_pair256_experiments.txt: the weights of both layers cross L2 -> CU once per 131 pixels): off unless asked for
+  int64_t pair256 = 0;
   // the rest
   int64_t tail_kernel = 0;          // dp_bottleneck_tail_nhwc: 1 = the tile kernel instead of the strip walker
   int64_t roi_tab = 1;              // dp_roi_align_nhwc: 0 = the per-sample kernel for every sampling ratio

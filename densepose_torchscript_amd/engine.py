@@ -477,7 +477,7 @@ class Engine:
         if prof:
             e1.record(torch.cuda.current_stream(self.device))
             nbytes = N * H * W * es * (t2.C + 2 * l3.cout + l1n.cout) + (l3.weight.numel() + l1n.weight.numel()) * es
-            self.prof.append(("bottleneck_pair128_kernel", flops, e0, e1, "%s+next conv1 %dx%dx%d->%d->%d" % (l3.name, H, W, t2.C, l3.cout, l1n.cout), nbytes))
+            self.prof.append(("bottleneck_pair%d_kernel" % l3.cin, flops, e0, e1, "%s+next conv1 %dx%dx%d->%d->%d" % (l3.name, H, W, t2.C, l3.cout, l1n.cout), nbytes))
         self.flops_last += flops
         return Act(out, N, H, W, l3.cout), Act(t1n, N, H, W, l1n.cout)
 
@@ -1009,7 +1009,7 @@ class Engine:
             pinned.copy_(st["det_counts"], non_blocking=True)
         else:
             # everything that changes the captured launch sequence is part of the key
-            key = (shape, hwc, slot, self.overlap_decoder, self.decoder_after_rpn_heads, self.fuse_bottleneck, self.fuse_rpn_head, self.fuse_stem_pool, self.fork_levels, self.nms_reference, self.decoder_fold, self.fuse_shortcut, self.fuse_sc_tail)
+            key = (shape, hwc, slot, self.overlap_decoder, self.decoder_after_rpn_heads, self.fuse_bottleneck, self.fuse_rpn_head, self.fuse_stem_pool, self.fork_levels, self.nms_reference, self.decoder_fold, self.fuse_shortcut, self.fuse_sc_tail, self.fuse_pair, self.group_deconv, self.split_k_on)
             entry = self._graphs.pop(key, None)
             if entry is None:
                 # every (stream slot / pipeline lane) of one geometry needs a graph of its own: never cap below the slots in use,

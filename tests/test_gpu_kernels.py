@@ -476,41 +476,53 @@ def test_bottleneck_tail_with_projection_shortcut(eng, dt, case):
 
 
 PAIR_CASES = [
-    # N, H, W of a res3-shaped pair (128 -> 512 -> 128)
-    (2, 100, 168),      # two frames at the headline geometry: 33600 pixels = 2100 steps over 256 workgroups (8 - 9 steps each)
-    (3, 13, 21),        # 819 pixels: fewer steps than workgroups, ragged last step
-    (1, 1, 1),          # a single pixel
-    (2, 37, 45),        # odd sizes, a few steps per workgroup
+    # Cmid, N, H, W of a res3-shaped pair (128 -> 512 -> 128) / a res4-shaped one (256 -> 1024 -> 256)
+    (128, 2, 100, 168),      # two frames at the headline geometry: 33600 pixels = 2100 steps over 256 workgroups (8 - 9 steps each)
+    (128, 3, 13, 21),        # 819 pixels: fewer steps than workgroups, ragged last step
+    (128, 1, 1, 1),          # a single pixel
+    (128, 2, 37, 45),        # odd sizes, a few steps per workgroup
+    (256, 8, 50, 84),        # res4 at the headline geometry: 33600 pixels = 2100 tiles: one round of 256 full jobs + 52 one-tile jobs
+    (256, 1, 50, 84),        # one frame: 263 tiles over 256 jobs of one or two tiles
+    (256, 3, 13, 21),        # 819 pixels: 52 jobs of one tile, ragged last tile
+    (256, 1, 1, 1),          # a single pixel
+    (256, 2, 37, 45),        # 209 tiles
+    (256, 5, 64, 70),        # 1400 tiles: jobs of five and six tiles (uneven pixel blocks)
 ]
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", PAIR_CASES)
-def test_bottleneck_pair_res3(eng, dt, case):
-    """dp_bottleneck_pair_nhwc: conv3 + residual + ReLU of a res3 block and conv1 + ReLU of the next one (resnet.py:199-205, :192-193)
-    in one launch. The block output is BIT-identical to the separate conv3 launch; the next block's conv1 output equals the separate
-    launch up to its summation order (eight 64-channel partial sums instead of one chain) and torch in fp64; every image alone equals the
-    image inside the batch bit for bit."""
+def test_bottleneck_pair_res3(eng, dt, case, policy):
+    """dp_bottleneck_pair_nhwc: conv3 + residual + ReLU of a res3 / res4 block and conv1 + ReLU of the next one (resnet.py:199-205, :192-193;
+    resnet.py:659-688 builds the blocks) in one launch - res3 with both matrices in registers (dp_pair.hip), res4 with both streamed
+    through LDS in 64-channel chunks (dp_pair256.hip). The block output is BIT-identical to the separate conv3 launch; the next block's conv1
+    output equals the separate launch up to its summation order and torch in fp64; every image alone equals the image inside the batch bit
+    for bit (the job split depends on the pixel count, a pixel's arithmetic does not)."""
     from densepose_torchscript_amd.engine import Act
     from densepose_torchscript_amd.pack import conv_from_oihw
     e = eng[dt]
-    N, H, W = case
-    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W)
+    Cm, N, H, W = case
+    Co = 4 * Cm
+    if Cm == 256:
+        assert e.bottleneck_pair is not None
+        policy.set("pair256", "1")       # the res4 form is off by default (slower than the two launches at the benchmark geometry)
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W + Cm)
     mk = lambda co, ci: torch.randn((co, ci, 1, 1), generator=g) * (1.0 / ci) ** 0.5  # noqa: E731
-    w3, w1 = _round(mk(512, 128), dt), _round(mk(128, 512), dt)
-    b3, b1 = torch.randn((512,), generator=g) * 0.5, torch.randn((128,), generator=g) * 0.5
-    l3 = conv_from_oihw("conv3", w3.numpy(), b3.numpy(), 128, 1, 0, 1, e.dt, e.device)
-    l1 = conv_from_oihw("conv1n", w1.numpy(), b1.numpy(), 512, 1, 0, 1, e.dt, e.device)
-    t2 = _round(F.relu(torch.randn((N, 128, H, W), generator=g)), dt)
-    res = _round(torch.randn((N, 512, H, W), generator=g), dt)
-    ta = Act(_nhwc(t2, 128, e.tdt, e.device), N, H, W, 128)
-    ra = Act(_nhwc(res, 512, e.tdt, e.device), N, H, W, 512)
+    w3, w1 = _round(mk(Co, Cm), dt), _round(mk(Cm, Co), dt)
+    b3, b1 = torch.randn((Co,), generator=g) * 0.5, torch.randn((Cm,), generator=g) * 0.5
+    l3 = conv_from_oihw("conv3", w3.numpy(), b3.numpy(), Cm, 1, 0, 1, e.dt, e.device)
+    l1 = conv_from_oihw("conv1n", w1.numpy(), b1.numpy(), Co, 1, 0, 1, e.dt, e.device)
+    t2 = _round(F.relu(torch.randn((N, Cm, H, W), generator=g)), dt)
+    res = _round(torch.randn((N, Co, H, W), generator=g), dt)
+    ta = Act(_nhwc(t2, Cm, e.tdt, e.device), N, H, W, Cm)
+    ra = Act(_nhwc(res, Co, e.tdt, e.device), N, H, W, Co)
     x_ref = e.conv(l3, ta, relu=True, residual=ra)
     n_ref = e.conv(l1, x_ref, relu=True)
     fused = e.bottleneck_pair(l3, l1, ta, ra)
-    assert fused is not None, "the library must have a fused kernel for the res3 shape"
+    assert fused is not None, "the library must have a fused kernel for the res3 / res4 shapes"
     x_f, n_f = fused
     torch.cuda.synchronize()
+    # the block output: one chain over K from the bias, + residual, ReLU - the separate conv3 launch's order in both forms
     assert torch.equal(x_f.t, x_ref.t)
     ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
     d = (n_f.t.float() - n_ref.t.float()).abs()
@@ -520,7 +532,7 @@ def test_bottleneck_pair_res3(eng, dt, case):
     got = n_f.t.float().cpu().permute(0, 3, 1, 2).double()
     assert bool(((got - y1).abs() <= ulp * y1.abs() + 2e-3).all()), float((got - y1).abs().max())
     for i in sorted({0, N - 1}):
-        one = e.bottleneck_pair(l3, l1, Act(ta.t[i:i + 1].contiguous(), 1, H, W, 128), Act(ra.t[i:i + 1].contiguous(), 1, H, W, 512))
+        one = e.bottleneck_pair(l3, l1, Act(ta.t[i:i + 1].contiguous(), 1, H, W, Cm), Act(ra.t[i:i + 1].contiguous(), 1, H, W, Co))
         torch.cuda.synchronize()
         assert torch.equal(one[0].t[0], x_f.t[i]) and torch.equal(one[1].t[0], n_f.t[i]), i
     # other widths and the fp32 parity mode have no fused kernel: the helper says so
@@ -741,6 +753,40 @@ def test_conv3x3_weight_stationary_equals_ring_kernel(eng, dt, shape, policy):
     ulp = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
     gd = got.t.float().cpu().permute(0, 3, 1, 2).double()
     assert bool(((gd - ref).abs() <= ulp * ref.abs() + 2e-3).all()), float((gd - ref).abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,res", [(1024, 256, False), (256, 1024, True), (2048, 512, False), (512, 256, "up")])
+def test_conv1x1_weight_stationary_pointwise_chunks_large_batches(eng, cin, cout, res, policy):
+    """Kernel class 9 is chosen by the channel counts alone (dp_conv_pws_ok looks at ONE image's size): a batch whose tensors pass the 32-bit
+    offset range is cut into image chunks inside dp_conv_pws_launch. With the limit lowered to two images the bits are the unchunked launch's,
+    with a linear residual and with the FPN's nearest x2 top-down map (per-image residual pointers)."""
+    from densepose_torchscript_amd import lib as L
+    from densepose_torchscript_amd.engine import Act
+    from densepose_torchscript_amd.pack import conv_from_oihw
+    e = eng["bf16"]
+    N, H, W = 5, 12, 22
+    g = torch.Generator().manual_seed(cin + cout)
+    x = Act(_round(torch.randn((N, H, W, cin), generator=g), "bf16").to(e.tdt).to(e.device), N, H, W, cin)
+    w = _round(torch.randn((cout, cin, 1, 1), generator=g) * (1.0 / cin) ** 0.5, "bf16")
+    layer = conv_from_oihw("c", w.numpy(), np.zeros(cout, np.float32), cin, 1, 0, 1, e.dt, e.device)
+    r, rshift = None, 0
+    if res == "up":
+        r, rshift = Act(_round(torch.randn((N, H // 2, W // 2, cout), generator=g), "bf16").to(e.tdt).to(e.device), N, H // 2, W // 2, cout), 1
+    elif res:
+        r = Act(_round(torch.randn((N, H, W, cout), generator=g), "bf16").to(e.tdt).to(e.device), N, H, W, cout)
+    p = L.ConvParams()
+    p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout, p.Cout_w, p.Kpad = H, W, cin, H, W, cout, layer.cout_w, layer.kpad
+    p.stride, p.ntaps, p.dtype = 1, 1, e.dt
+    p.osN, p.osH, p.osW = H * W * cout, W * cout, cout
+    p.out = 4096
+    for n in (1, 5, 4000):
+        p.N = n
+        assert e.lib.dp_conv2d_kernel_class(C.byref(p)) == 9, n       # whatever the batch: also one whose tensors are far beyond 2 GiB
+    whole = e.conv(layer, x, relu=True, residual=r, rshift=rshift).t.clone()
+    policy.set("rows_chunk_bytes", str(2 * (H * W + 64) * max(cin, cout) * 2))
+    parts = e.conv(layer, x, relu=True, residual=r, rshift=rshift).t
+    torch.cuda.synchronize()
+    assert torch.equal(whole, parts)
 
 
 WSQ_CASES = [(1, 13, 21, True), (2, 9, 17, False), (3, 37, 45, True), (1, 8, 16, True), (2, 25, 42, True), (1, 50, 84, True), (2, 64, 35, False),

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../densepose_torchscript_amd/csrc"
 B=../../build
 mkdir -p $B/obj
 unit=$1; tag=$2; shift 2
-ALL="dp_conv dp_conv_ws dp_conv_wq dp_conv_rows dp_conv_pw dp_bottleneck dp_pair dp_stem dp_ops dp_detect dp_extra"
+ALL="dp_conv dp_conv_ws dp_conv_wq dp_conv_rows dp_conv_pw dp_bottleneck dp_pair dp_pair256 dp_stem dp_ops dp_detect dp_extra"
 objs=""
 for f in $ALL; do
   if [ $f != $unit ]; then
