@@ -153,12 +153,13 @@ def r_sensitivity(args, state, frames, device):
     """images/s of the same workload with the detection count pinned to R = 0 and to R = 100 per image (the
     DensePose head costs 28.7 GFLOP per detection, so the result is linear in R; the headline runs at R = 8)."""
     from densepose_torchscript_amd import get_config
+    from densepose_torchscript_amd.options import EngineOptions
     from densepose_torchscript_amd.predictor import DensePosePredictor
     out = {}
     for label, opts in (("R0", ["TEST.DETECTIONS_PER_IMAGE", 8, "MODEL.ROI_HEADS.SCORE_THRESH_TEST", 2.0]),
                         ("R100", ["TEST.DETECTIONS_PER_IMAGE", 100, "MODEL.ROI_HEADS.SCORE_THRESH_TEST", 0.0])):
         cfg = get_config(args.config, opts)
-        p = DensePosePredictor(cfg, state, dtype=args.dtype, device=device, resize="device", use_graphs=not args.no_graphs)
+        p = DensePosePredictor(cfg, state, dtype=args.dtype, device=device, resize="device", use_graphs=not args.no_graphs, options=EngineOptions.from_env())
         p.pipeline_depth = args.pipeline
         for _ in range(4):
             res = p.predict_batch(frames)
@@ -311,7 +312,7 @@ def main():
         for k in state:
             if k.endswith("running_var"):
                 state[k] += 1.0
-    pred = DensePosePredictor(cfg, state, dtype=args.dtype, device=device, resize="device", num_streams=args.streams, use_graphs=not args.no_graphs)
+    pred = DensePosePredictor(cfg, state, dtype=args.dtype, device=device, resize="device", num_streams=args.streams, use_graphs=not args.no_graphs, options=EngineOptions.from_env())
     bcast_s, bcast_bytes = 0.0, 0
     if world > 1:
         tensors = pred.engine.model.parameter_tensors()
@@ -511,7 +512,7 @@ def main():
                                       "ms_per_step": round(1e3 * ft / args.steps, 3)}
 
     # ... and so is the weight-stationary 3x3 kernel (instances per channel count and ReLU flag)
-    fam = [v for c, v in agg.items() if c.startswith(("conv3x3_wsr_kernel<", "conv3x3_wsq_kernel<"))]      # kernel classes 6 and 10
+    fam = [v for c, v in agg.items() if c.startswith(("conv3x3_wsr_kernel<", "conv3x3_wsq_kernel<", "conv3x3_ws1_kernel<"))]      # kernel classes 6 and 10
     if fam:
         ff, ft, fc = sum(v[0] for v in fam), sum(v[1] for v in fam), sum(v[2] for v in fam)
         roofline["wsr_family"] = {"tflops": round(ff / ft / 1e12, 2), "frac": round(ff / ft / peak, 4), "calls_per_step": fc // args.steps,

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from .config import ModelConfig, get_config
 from .engine import Engine
+from .options import EngineOptions
 from .resize import resize_u8_device_batch
 from .weights import check_state, load_checkpoint
 
@@ -83,8 +84,9 @@ class _HostFrameRing:
 
 class DensePosePredictor:
     def __init__(self, cfg, weights, dtype="bf16", device="cuda:0", resize="host", num_streams=1, use_graphs=False, check_keep=False,
-                 pipeline_depth=1, nms_reference="cpu"):
-        """cfg: ModelConfig | variant name | yaml path. weights: path to .pkl/.pth or a canonical state dict."""
+                 pipeline_depth=1, nms_reference="cpu", options=None):
+        """cfg: ModelConfig | variant name | yaml path. weights: path to .pkl/.pth or a canonical state dict.
+        options: options.EngineOptions (the A/B switches; default = what the product runs; nothing here reads the environment)."""
         if not isinstance(cfg, ModelConfig):
             cfg = get_config(cfg)
         self.cfg = cfg
@@ -94,7 +96,8 @@ class DensePosePredictor:
         self.input_format = cfg.input_format
         self.min_size = cfg.min_size
         self.max_size = cfg.max_size
-        self.engine = Engine(cfg, state, dtype=dtype, device=device)
+        self.options = options if options is not None else EngineOptions()
+        self.engine = Engine(cfg, state, dtype=dtype, device=device, options=self.options)
         self.device = self.engine.device
         self.resize_mode = resize  # "host": torch CPU uint8 kernel exactly as the reference (Q4) ; "device": HIP kernel
         self.num_streams = num_streams  # sub-batches of a batch run concurrently on this many HIP streams
@@ -116,8 +119,8 @@ class DensePosePredictor:
         self._lanes, self._next_lane = [], 0
         self._last_done = []   # completion events of the most recent predict_batch call (one per frame group)
         self._host_ring = None  # _HostFrameRing, created on the first host-resident frame
-        import os as _os
-        self.fuse_resize = _os.environ.get("DP_FUSE_RESIZE", "1") != "0"   # device resize at scale != 1: fused with the preprocess (A/B knob)
+        self.fuse_resize = bool(self.options.fuse_resize)            # device resize at scale != 1: fused with the preprocess
+        self.identity_resize = bool(self.options.identity_resize)    # frames that already have the test size skip the two resize passes
 
     # -- defaults.py:76-89 ---------------------------------------------------------------------------------
     def _to_chw(self, original_image, bgr):
@@ -145,9 +148,7 @@ class DensePosePredictor:
             # permuted views of contiguous HWC frames are resized straight from HWC
             hwc = all(c.stride(0) == 1 and c.stride(2) == 3 for c in chws)
             views = [(c.permute(1, 2, 0) if hwc else c) for c in chws]
-            import os as _os     # DP_IDENTITY_RESIZE=0: A/B knob (run the two resize passes even at scale 1)
-            identity = (hwc and k == 1.0 and output_size(height, width, k) == (height, width)
-                        and _os.environ.get("DP_IDENTITY_RESIZE", "1") != "0")
+            identity = hwc and k == 1.0 and output_size(height, width, k) == (height, width) and self.identity_resize
             if all(not v.is_cuda for v in views):
                 # host-resident frames (the reference's boundary): pinned ring + one H2D per batch on the copy stream
                 if self._host_ring is None:

@@ -30,10 +30,8 @@ def _load_roctx():
 
 
 class StageTrace:
-    def __init__(self, device, roctx=None, timers=True):
+    def __init__(self, device, roctx=False, timers=True):
         self.device = torch.device(device)
-        if roctx is None:
-            roctx = os.environ.get("DP_ROCTX", "0") == "1"
         self.roctx = _load_roctx() if roctx else None
         self.timers = timers
         self.records = []   # (stage name, start event, end event, flops)

@@ -60,13 +60,12 @@ def main():
     ap.add_argument("--fp16", action="store_true", help="IEEE half operands (the reference's export.py --fp16 / run.py default on GPU)")
     ap.add_argument("--min_score", type=float, default=0.3)
     ap.add_argument("--batch", type=int, default=8, help="frames per batch for a [T,H,W,3] .npy input")
+    ap.add_argument("--opts", nargs="*", default=[], metavar="KEY VALUE", help="config overrides like the reference's `opts` (detectron2 yacs keys)")
     args = ap.parse_args()
     from densepose_torchscript_amd import get_config, make_synthetic_state
     from densepose_torchscript_amd.predictor import DensePosePredictor
     from densepose_torchscript_amd.visualizer import extract_iuv, iuv_image
-    import os
-    extra = os.environ.get("DP_RUN_OPTS", "").split()     # extra "KEY value" overrides (tests: tiny widths)
-    extra = [int(v) if v.lstrip("-").isdigit() else v for v in extra]
+    extra = [int(v) if v.lstrip("-").isdigit() else v for v in args.opts]     # extra "KEY value" overrides (tests: tiny widths)
     cfg = get_config(args.config, extra + ["MODEL.ROI_HEADS.SCORE_THRESH_TEST", args.min_score])
     weights = args.weights
     if weights.startswith("synthetic"):

@@ -168,3 +168,23 @@ def test_policy_table_and_no_environment_reads(built, monkeypatch):
     assert lib.dp_conv2d_kernel_class(ctypes.byref(p)) == 9
     p.dtype = built.DP_F32                         # fp32 parity mode stays on the exact-fp32 kernels
     assert lib.dp_conv2d_kernel_class(ctypes.byref(p)) != 9
+
+
+def test_product_reads_no_environment_for_its_switches(monkeypatch):
+    """The A/B switches of the host side are constructor arguments (options.EngineOptions), not environment variables: the only os.environ uses
+    under densepose_torchscript_amd/ are the policy-table variables lib.py applies ONCE at load for the command-line tools, the rank variables
+    of torch.distributed in parallel.py, and EngineOptions.from_env - which the tools call explicitly."""
+    import re
+    pkg = os.path.join(ROOT, "densepose_torchscript_amd")
+    allowed = {"lib.py", "parallel.py", "options.py"}
+    for fn in sorted(os.listdir(pkg)):
+        if fn.endswith(".py") and fn not in allowed:
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"os\.environ|getenv", src), fn
+    from densepose_torchscript_amd.options import EngineOptions
+    assert EngineOptions() == EngineOptions.from_env({})
+    monkeypatch.setenv("DP_FUSE_PAIR", "0")
+    assert EngineOptions().fuse_pair is True                      # the default does not look at the environment ...
+    o = EngineOptions.from_env()
+    assert o.fuse_pair is False and o.fork_levels == 2           # ... the tools' constructor does
+    assert EngineOptions.from_env({"DP_FORK": "3", "DP_DECODER_FOLD": "0"}) == EngineOptions(fork_levels=3, decoder_fold=False)

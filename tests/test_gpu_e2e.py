@@ -205,7 +205,7 @@ def test_full_width_network_runs_on_the_documented_kernel_classes():
         assert all(c.startswith(("conv1x1_pws_kernel", "conv1x1_pwq_kernel")) for c in cls_of(lname)), (lname, cls_of(lname))
     assert all(c == "bottleneck_pair128_kernel" for c in cls_of("res3.1.conv3")), cls_of("res3.1.conv3")
     assert all(c == "bottleneck_tail64_kernel" for c in cls_of("res2.1.conv2")), cls_of("res2.1.conv2")
-    assert all(c.startswith("conv3x3_wsq") for c in cls_of("res4.2.conv2")), cls_of("res4.2.conv2")      # kernel class 10 (dp_conv_wq.hip)
+    assert all(c.startswith("conv3x3_ws1") for c in cls_of("res4.2.conv2")), cls_of("res4.2.conv2")      # kernel class 10 (dp_conv_wq.hip)
     assert all(c.startswith("conv3x3_wsr_kernel<128") for c in cls_of("res3.1.conv2")), cls_of("res3.1.conv2")
     dec = cls_of("dp_predictor")      # one grouped launch where the LDS-ring kernels take the shape, else the four launches
     assert (len(dec) == 1 and dec[0].endswith(",x4>")) or len(dec) == 4, dec
@@ -550,11 +550,10 @@ def test_run_cli_frame_sequence_equals_single_frames(tmp_path):
     rng = np.random.default_rng(21)
     frames = rng.integers(0, 256, (5, 96, 160, 3), dtype=np.uint8)
     np.save(tmp_path / "clip.npy", frames)
-    # a tiny yaml-free config: the CLI accepts a variant name only, so the overrides travel through the environment
-    env = dict(os.environ, DP_RUN_OPTS=" ".join(str(o) for o in TINY_OPTS))
+    # a tiny yaml-free config: the CLI accepts a variant name + `--opts KEY VALUE ...` overrides
     def run(inp, out):
         subprocess.check_call([sys.executable, os.path.join(root, "run.py"), "densepose_rcnn_R_50_FPN_s1x", "synthetic:4", str(inp),
-                               "--out", str(out), "--fp32", "--batch", "2", "--min_score", "0.05"], env=env, cwd=root)
+                               "--out", str(out), "--fp32", "--batch", "2", "--min_score", "0.05", "--opts"] + [str(o) for o in TINY_OPTS], cwd=root)
         return np.load(out)
     seq = run(tmp_path / "clip.npy", tmp_path / "seq.npz")["iuv"]
     assert seq.shape == (5, 3, 96, 160)

@@ -5,12 +5,13 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np, torch
 from conftest import golden_case_inputs, load_golden
+from densepose_torchscript_amd.options import EngineOptions
 from densepose_torchscript_amd.predictor import DensePosePredictor
 from test_gpu_e2e import IUV_KEYS, _label_agreement, _match_to_reference
 name, dt = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "bf16")
 meta, z = load_golden(name)
 cfg, state, img = golden_case_inputs(meta)
-pred = DensePosePredictor(cfg, state, dtype=dt)
+pred = DensePosePredictor(cfg, state, dtype=dt, options=EngineOptions.from_env())
 out = {k: v.cpu() for k, v in pred(torch.from_numpy(img)).items()}
 s = meta["iuv_stride"]
 gb, gs, rb, rs = out["pred_boxes"].numpy(), out["scores"].numpy(), z["out/pred_boxes"], z["out/scores"]

@@ -2,11 +2,12 @@
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, time
 from densepose_torchscript_amd import get_config, make_synthetic_state
+from densepose_torchscript_amd.options import EngineOptions
 from densepose_torchscript_amd.predictor import DensePosePredictor
 dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 cfg = get_config("densepose_rcnn_R_50_FPN_s1x", ["TEST.DETECTIONS_PER_IMAGE", 8])
-pred = DensePosePredictor(cfg, make_synthetic_state(cfg, 0), dtype=dtype, resize="device", num_streams=1)
+pred = DensePosePredictor(cfg, make_synthetic_state(cfg, 0), dtype=dtype, resize="device", num_streams=1, options=EngineOptions.from_env())
 frames = [torch.from_numpy(np.random.default_rng(1234 + i).integers(0, 256, (800, 1333, 3), dtype=np.uint8)).cuda() for i in range(batch)]
 for _ in range(2): pred.predict_batch(frames)
 torch.cuda.synchronize()
