@@ -3,6 +3,7 @@ preprocess, ResNet + FPN, RPN + proposal selection, box branch, DensePose decode
 launch glue is engine_ops.LayerOps, streams / graphs / the two phases of a batch step are engine.py."""
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import lib as L
@@ -201,7 +202,12 @@ class Stages:
         ws = self._empty((self.lib.dp_nms_workspace_bytes(n, slots),), torch.uint8)
         p = L.NmsParams()
         p.boxes, p.scores, p.group, p.valid = boxes.data_ptr(), scores.data_ptr(), group.data_ptr(), valid.data_ptr()
-        p.n_img, p.n_slots, p.iou_thr, p.max_out, p.trick_max_numel = n, slots, thr, max_out, NMS_TRICK_MAX_NUMEL[self.nms_reference]
+        # torchvision's CPU kernel compares the float IoU with the DOUBLE threshold (nms_kernel.cpp); the float compare of dp_batched_nms is
+        # the same predicate when it gets the largest float not above the configured value (0.7 -> 0.699999988; float(0.3) would round up)
+        thr32 = np.float32(thr)
+        if float(thr32) > float(thr):
+            thr32 = np.nextafter(thr32, np.float32(-np.inf))
+        p.n_img, p.n_slots, p.iou_thr, p.max_out, p.trick_max_numel = n, slots, float(thr32), max_out, NMS_TRICK_MAX_NUMEL[self.nms_reference]
         p.out_boxes, p.out_scores, p.out_index, p.out_count = out_boxes.data_ptr(), out_scores.data_ptr(), out_index.data_ptr(), out_count.data_ptr()
         p.workspace = ws.data_ptr()
         L.check(self.lib.dp_batched_nms(C.byref(p), self._stream()), "dp_batched_nms")

@@ -324,7 +324,8 @@ int dp_rpn_topk_decode_levels(const dp_rpn_level_params* levels, int n_levels, d
 typedef struct {
   const float* boxes; const float* scores; const int32_t* group; const int32_t* valid;
   int32_t n_img, n_slots;
-  float iou_thr;
+  float iou_thr;        /* suppressed iff iou > iou_thr, in float. torchvision's CPU kernel compares the float IoU with its DOUBLE threshold
+                           (nms_kernel.cpp): a caller holding a double passes the largest float not above it - the same predicate */
   int32_t max_out;
   int32_t trick_max_numel;
   float* out_boxes;     /* [n_img][max_out][4] */

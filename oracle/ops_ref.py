@@ -59,6 +59,17 @@ def roi_align(input, rois, output_size, spatial_scale=1.0, sampling_ratio=-1, al
     return _roi_align_torch(input, rois, output_size, spatial_scale, sampling_ratio, aligned)
 
 
+def nms_threshold_f32(iou_threshold):
+    """torchvision's CPU kernel (torchvision 0.16.2 csrc/ops/cpu/nms_kernel.cpp: `auto ovr = inter / (...); if (ovr > iou_threshold)`) compares
+    the FLOAT IoU with the DOUBLE threshold. For a float x:  x > t_double  <=>  x > the largest float not above t_double - so the whole
+    comparison can stay in float when the threshold is rounded DOWN (0.7 -> 0.699999988, 0.5 exact; a plain float(0.3) = 0.300000012 would keep
+    a pair whose IoU is exactly that float where torchvision suppresses it)."""
+    t = np.float32(iou_threshold)
+    if float(t) > float(iou_threshold):
+        t = np.nextafter(t, np.float32(-np.inf))
+    return np.float32(t)
+
+
 def nms(boxes, scores, iou_threshold, backend=None):
     use_c = (_C is not None) if backend is None else (backend == "c")
     if use_c and boxes.shape[0] > 0:
@@ -66,7 +77,7 @@ def nms(boxes, scores, iou_threshold, backend=None):
         order = torch.sort(scores.detach().to(torch.float32), descending=True, stable=True)[1].contiguous()
         keep = torch.empty((b.shape[0],), dtype=torch.int64)
         nk = _C.oracle_nms_f32(ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(order.data_ptr()), int(b.shape[0]),
-                               ctypes.c_float(iou_threshold), ctypes.c_void_p(keep.data_ptr()))
+                               ctypes.c_float(float(nms_threshold_f32(iou_threshold))), ctypes.c_void_p(keep.data_ptr()))
         return keep[:nk].clone()
     return _nms_numpy(boxes, scores, iou_threshold)
 
@@ -166,7 +177,7 @@ def _nms_numpy(boxes, scores, iou_threshold):
     order = torch.sort(s, descending=True, stable=True)[1].numpy()
     x1, y1, x2, y2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
     areas = (x2 - x1) * (y2 - y1)
-    thr = np.float32(iou_threshold)
+    thr = nms_threshold_f32(iou_threshold)
     suppressed = np.zeros(n, dtype=bool)
     keep = []
     zero = np.float32(0)
