@@ -28,11 +28,12 @@ def run_pair(name, dtype):
     torch.cuda.synchronize()
     out = {k: v.cpu() for k, v in out.items()}
     inter = eng.inter
-    fused = eng.fused_shortcut_blocks()
-    fold = bool(inter.get("decoder_fold", False))
-    em = StorageOracle(cfg, state, dtype, fused_shortcuts=fused, decoder_fold=fold)
+    em = StorageOracle(cfg, state, dtype)
     image, height, width = em.resize(torch.from_numpy(img))
     images, padding = em.preprocess(image)
+    # which rounding points the engine removes is DERIVED (oracle/structure.py, from the configuration and the padded frame size), not read off
+    # the engine - and the engine has to agree
+    fused, fold = derived_fusions(em, cfg, dtype, images, eng)
     feats = em.backbone(images)
     stages = {k: (_nchw(inter[k])[:, : feats[k].shape[1]], feats[k]) for k in ("p2", "p3", "p4", "p5", "p6")}
     det_boxes, det_scores, det_counts = inter["detections"]
@@ -46,6 +47,17 @@ def run_pair(name, dtype):
         for k, t in zip(IUV_KEYS, dp):
             stages[k] = (out[k], t)
     return dict(meta=meta, z=z, cfg=cfg, out=out, em_iuv=dict(zip(IUV_KEYS, dp)), stages=stages, R=R, fold=fold, fused=fused)
+
+
+def derived_fusions(em, cfg, dtype, images, eng):
+    """oracle/structure.rounding_point_fusions for this case, installed in the oracle `em`; asserts that the engine decided the same."""
+    from oracle.structure import rounding_point_fusions
+    fused, fold = rounding_point_fusions(cfg, dtype, tuple(int(v) for v in images.shape[-2:]))
+    assert sorted(fused) == sorted(eng.fused_shortcut_blocks()), (fused, eng.fused_shortcut_blocks())
+    if cfg.dp_decoder_on:
+        assert fold == bool(eng.inter.get("decoder_fold", False)), (fold, eng.inter.get("decoder_fold"))
+    em.fused_shortcuts, em.decoder_fold = set(fused), bool(fold)
+    return fused, fold
 
 
 def stage_stats(got, ref, dtype):
@@ -109,6 +121,7 @@ def run_forced(name, dtype, engine_opts=None):
     for k, v in (engine_opts or {}).items():      # per-layer choices that move a rounding point (the oracle mirrors them)
         assert hasattr(eng, k), k
         setattr(eng, k, v)
+    derive = not engine_opts      # default switches: the oracle derives the engine's rounding-point fusions itself (and checks them)
     eng.keep_intermediates = True
     rec = {}
     conv0, gn0 = eng.conv, eng.groupnorm
@@ -138,8 +151,7 @@ def run_forced(name, dtype, engine_opts=None):
     eng.conv, eng.groupnorm, eng.bottleneck_pair = conv, groupnorm, pair
     out = {k: v.cpu() for k, v in pred(torch.from_numpy(img)).items()}
     torch.cuda.synchronize()
-    fused = eng.fused_shortcut_blocks()
-    em = StorageOracle(cfg, state, dtype, fused_shortcuts=fused, decoder_fold=bool(eng.inter.get("decoder_fold", False)))
+    em = StorageOracle(cfg, state, dtype)
     det_boxes, det_scores, det_counts = eng.inter["detections"]
     R = int(det_counts[0])
     # engine layer names -> the oracle's: the RPN's 1x1 heads are one 16-channel layer in the engine, two in the reference (not forced:
@@ -157,6 +169,10 @@ def run_forced(name, dtype, engine_opts=None):
     em.force = force
     image, height, width = em.resize(torch.from_numpy(img))
     images, padding = em.preprocess(image)
+    if derive:
+        derived_fusions(em, cfg, dtype, images, eng)
+    else:       # the engine runs with switches the design does not describe (a test turned fusions off): the oracle is told
+        em.fused_shortcuts, em.decoder_fold = set(eng.fused_shortcut_blocks()), bool(eng.inter.get("decoder_fold", False))
     feats = em.backbone(images)
     em.rpn_head([feats[k] for k in ("p2", "p3", "p4", "p5", "p6")])
     iuv_stats, lab = {}, (0, 0, 0.0)

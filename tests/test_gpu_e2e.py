@@ -232,7 +232,10 @@ BF16_LABEL_FLOOR = {"tiny_r50_s1x_a": 0.97, "full_r50_s1x_small": 0.93, "full_r5
 # detection: one box at the image corner moves by 0.27 px and its maps by 0.19 of their range). The reference's OWN bf16 run reads 0.223
 # on this case (tests/golden/full_r50_s1x_small__bf16.npz, tests/yardstick.py) and matches 2 of 4 boxes where this engine matches 3:
 # the band is 1.25 x that, the reference-derived test below holds the engine to it case by case.)
-BF16_IUV_BAND = {"tiny_r50_s1x_a": 0.05, "full_r50_s1x_small": 0.28, "full_r50_s1x_800x1333": 0.3}
+# round 6 (tools/band_values.py, profiles/r6_band_values.txt; the kernels are deterministic, the numbers are the same on every box): 0.0167 / 0.2020 /
+# 0.0373 with 3 of 3 / 3 of 4 / 7 of 8 detections matched - held to 1.25 x that. The storage-emulating oracle (per layer, teacher forced) carries
+# the parity claim for the 16-bit modes; these bands only catch a regression of the whole.
+BF16_IUV_BAND = {"tiny_r50_s1x_a": 0.021, "full_r50_s1x_small": 0.2525, "full_r50_s1x_800x1333": 0.0467}
 FP16_LABEL_FLOOR = 0.9
 
 
