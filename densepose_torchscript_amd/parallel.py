@@ -39,10 +39,29 @@ def _parse_cpulist(text):
     return cpus
 
 
-def gpu_numa_cpus(local_rank, sysfs="/sys"):
-    """CPUs of the NUMA node GPU `local_rank` hangs off: the local_rank-th render device in PCI-address order
-    (/sys/class/drm/card*/device/numa_node -> /sys/devices/system/node/node<N>/cpulist). None when sysfs does not say
-    (numa_node = -1 on single-node hosts, containers without the files)."""
+def visible_device_index(local_rank, env=None):
+    """The physical GPU index behind HIP device `local_rank`: HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES re-number
+    the devices a process sees (the launcher of a shared box hands every job its own subset); sysfs lists the physical ones. Integer lists
+    only (UUID forms are not resolved: -> local_rank). Read from the environment without touching the GPU: a rank pins itself BEFORE it
+    creates its context."""
+    env = os.environ if env is None else env
+    idx = local_rank
+    # HIP device i = entry i of HIP_VISIBLE_DEVICES (CUDA_VISIBLE_DEVICES is its alias) among the devices ROCr shows, which are the entries of
+    # ROCR_VISIBLE_DEVICES among the physical ones
+    for var in ("HIP_VISIBLE_DEVICES" if env.get("HIP_VISIBLE_DEVICES", "").strip() else "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = env.get(var, "").strip()
+        if not v:
+            continue
+        parts = [p.strip() for p in v.split(",") if p.strip() != ""]
+        if not all(p.isdigit() for p in parts) or idx >= len(parts):
+            return local_rank
+        idx = int(parts[idx])
+    return idx
+
+
+def gpu_numa_node(local_rank, sysfs="/sys", env=None):
+    """NUMA node of the GPU behind HIP device `local_rank`: the visible_device_index-th AMD render device in PCI-address order
+    (/sys/class/drm/card*/device/numa_node). None when sysfs does not say (numa_node = -1 on single-node hosts, containers without the files)."""
     import glob
     cards = []
     for dev in glob.glob(os.path.join(sysfs, "class/drm/card[0-9]*/device")):
@@ -56,31 +75,56 @@ def gpu_numa_cpus(local_rank, sysfs="/sys"):
         except OSError:
             continue
     cards.sort()
-    if local_rank >= len(cards):
+    phys = visible_device_index(local_rank, env)
+    if phys >= len(cards):
         return None
     try:
-        node = int(open(os.path.join(cards[local_rank][1], "numa_node")).read().strip())
-        if node < 0:
-            return None
+        node = int(open(os.path.join(cards[phys][1], "numa_node")).read().strip())
+        return node if node >= 0 else None
+    except (OSError, ValueError):
+        return None
+
+
+def gpu_numa_cpus(local_rank, sysfs="/sys", env=None):
+    """CPUs of the NUMA node GPU `local_rank` hangs off (/sys/devices/system/node/node<N>/cpulist), None when unknown."""
+    node = gpu_numa_node(local_rank, sysfs, env)
+    if node is None:
+        return None
+    try:
         return _parse_cpulist(open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)).read()) or None
     except (OSError, ValueError):
         return None
 
 
-def plan_rank_cpus(local_rank, local_world, allowed, numa_cpus=None):
+def plan_rank_cpus(local_rank, local_world, allowed, numa_cpus=None, node_of_rank=None):
     """The host CPUs rank `local_rank` of `local_world` on this node may run on: its GPU's NUMA node's CPUs (when known) restricted
     to what the process is allowed, split evenly among the ranks that share that node - or, without NUMA information, an even
-    contiguous split of the allowed CPUs. Never empty: a share smaller than one CPU falls back to the whole allowed set."""
+    contiguous split of the allowed CPUs. node_of_rank: the NUMA node of EVERY local rank's GPU (list, None entries = unknown): the
+    ranks that share this rank's node and its position among them are read off that list (ranks of a node need not be contiguous nor
+    evenly spread); without it the ranks are assumed to be spread evenly over the nodes. A rank whose own node is unknown while
+    others' are known takes an even split of the CPUs of no known node (so that it overlaps nobody). Never empty: a share smaller than
+    one CPU falls back to the whole allowed set."""
     allowed = sorted(allowed)
-    pool = sorted(set(allowed) & set(numa_cpus)) if numa_cpus else allowed
-    if not pool:
-        pool = allowed
-    # ranks that share this pool: without per-rank NUMA knowledge of the others, assume the ranks are spread evenly over the pools
-    n_pools = max(1, len(allowed) // max(len(pool), 1))
-    sharers = max(1, -(-local_world // n_pools))
-    idx = local_rank % sharers if numa_cpus else local_rank
-    if not numa_cpus:
-        sharers = local_world
+    if node_of_rank is not None and len(node_of_rank) == local_world and any(n is not None for n in node_of_rank):
+        mine = node_of_rank[local_rank]
+        same = [r for r in range(local_world) if node_of_rank[r] == mine]
+        if mine is not None and numa_cpus:
+            pool = sorted(set(allowed) & set(numa_cpus)) or allowed
+        else:
+            pool = allowed          # caller passes the CPUs of no known node when it has them (pin_rank_to_cpus)
+            if numa_cpus:
+                pool = sorted(set(allowed) & set(numa_cpus)) or allowed
+        idx, sharers = same.index(local_rank), len(same)
+    else:
+        pool = sorted(set(allowed) & set(numa_cpus)) if numa_cpus else allowed
+        if not pool:
+            pool = allowed
+        # ranks that share this pool: without per-rank NUMA knowledge of the others, assume the ranks are spread evenly over the pools
+        n_pools = max(1, len(allowed) // max(len(pool), 1))
+        sharers = max(1, -(-local_world // n_pools))
+        idx = local_rank % sharers if numa_cpus else local_rank
+        if not numa_cpus:
+            sharers = local_world
     per = len(pool) // sharers
     if per < 1:
         return allowed
@@ -99,21 +143,36 @@ def pin_rank_to_cpus(local_rank=None, local_world=None):
     if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return None
     allowed = sorted(os.sched_getaffinity(0))
-    cpus = plan_rank_cpus(local_rank, local_world, allowed, gpu_numa_cpus(local_rank))
+    nodes = [gpu_numa_node(r) for r in range(local_world)]
+    numa = gpu_numa_cpus(local_rank)
+    if nodes[local_rank] is None and any(n is not None for n in nodes):
+        # this rank's GPU says nothing while others do: stay off the CPUs of the nodes the others pinned themselves to
+        taken = set()
+        for n in set(x for x in nodes if x is not None):
+            try:
+                taken |= set(_parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % n).read()))
+            except (OSError, ValueError):
+                pass
+        numa = sorted(set(allowed) - taken) or None
+    cpus = plan_rank_cpus(local_rank, local_world, allowed, numa, node_of_rank=nodes)
     os.sched_setaffinity(0, cpus)
     torch.set_num_threads(max(1, min(len(cpus), 16)))
     return cpus
 
 
 def host_workers(default=4):
-    """Worker threads of a rank's host-side frame gather (predictor._HostFrameRing): the single-process default divided among the
-    ranks of this node, at least one."""
+    """Worker threads of a rank's host-side frame gather (predictor._HostFrameRing): `default` for a single process; for one rank of several,
+    one per eight CPUs of the share the rank is pinned to (pin_rank_to_cpus ran first: sched_getaffinity IS the share) - 4 on the 32-CPU
+    share of an 8-rank run on a 256-thread host, never more than `default`, at least one. (Unmeasured on an 8-GPU node: SCALE_rNN.json has
+    been `skipped` every round.)"""
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     try:
         n_cpus = len(os.sched_getaffinity(0))
     except AttributeError:
         n_cpus = os.cpu_count() or 1
-    return max(1, min(default, n_cpus, max(1, (default * 2) // max(local_world, 1)) if local_world > 1 else default))
+    if local_world <= 1:
+        return max(1, min(default, n_cpus))
+    return max(1, min(default, n_cpus // 8 if n_cpus >= 8 else 1))
 
 
 def shard_range(n_items, rank, world):

@@ -198,3 +198,14 @@ def test_rank_cpu_plan():
     assert plan_rank_cpus(5, 8, [0, 1, 2]) == [0, 1, 2]                  # fewer CPUs than ranks: no pinning below one CPU
     assert gpu_numa_cpus(0, sysfs="/nonexistent") is None
     assert host_workers(4) >= 1
+    # the NUMA node of EVERY rank's GPU known: ranks of a node need not be contiguous or evenly spread (5 GPUs on node 0, 3 on node 1, interleaved)
+    nodes = [0, 1, 0, 0, 1, 0, 1, 0]
+    shares = [plan_rank_cpus(r, 8, allowed, node0 if nodes[r] == 0 else node1, node_of_rank=nodes) for r in range(8)]
+    assert all(shares) and len(set(c for sh in shares for c in sh)) == sum(len(sh) for sh in shares)      # disjoint
+    assert all(set(sh) <= set(node0 if nodes[r] == 0 else node1) for r, sh in enumerate(shares))
+    assert len(shares[0]) == len(node0) // 5 and len(shares[1]) == len(node1) // 3
+    # HIP_VISIBLE_DEVICES re-numbers the devices: HIP device 1 of "2,5" is physical GPU 5; ROCR filters first
+    from densepose_torchscript_amd.parallel import visible_device_index
+    assert visible_device_index(1, {"HIP_VISIBLE_DEVICES": "2,5"}) == 5
+    assert visible_device_index(0, {"ROCR_VISIBLE_DEVICES": "4,6", "HIP_VISIBLE_DEVICES": "1"}) == 6
+    assert visible_device_index(3, {}) == 3 and visible_device_index(1, {"HIP_VISIBLE_DEVICES": "GPU-abc,GPU-def"}) == 1

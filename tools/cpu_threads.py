@@ -1,5 +1,5 @@
 """The CPU baseline (oracle/ref_cpu.py, the port bench.py times) at several thread counts on this box's host cores, incl. nproc: bench.py
-caps the baseline at 32 threads because torch's CPU convolutions stop scaling - and then collapse - beyond that on this class of host;
+used to cap the baseline at 32 threads (round 4; bench.py now uses the count that serves it best: 16) because torch's CPU convolutions stop scaling - and then collapse - beyond that on this class of host;
 this prints the evidence (profiles/r5_cpu_threads.txt).   usage: cpu_threads.py [frames per setting]"""
 import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
