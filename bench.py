@@ -276,6 +276,7 @@ def main():
 
     from densepose_torchscript_amd import get_config, make_synthetic_state
     from densepose_torchscript_amd import parallel
+    from densepose_torchscript_amd.options import EngineOptions
     from densepose_torchscript_amd.predictor import DensePosePredictor
     from densepose_torchscript_amd.weights import param_shapes
     import torch.distributed as dist

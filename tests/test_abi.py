@@ -188,3 +188,37 @@ def test_product_reads_no_environment_for_its_switches(monkeypatch):
     o = EngineOptions.from_env()
     assert o.fuse_pair is False and o.fork_levels == 2           # ... the tools' constructor does
     assert EngineOptions.from_env({"DP_FORK": "3", "DP_DECODER_FOLD": "0"}) == EngineOptions(fork_levels=3, decoder_fold=False)
+
+
+def test_entry_scripts_have_no_undefined_names():
+    """bench.py / run.py / __graft_entry__.py only run on the GPU box: a name used in a function but imported in another one (a round-6 slip in
+    bench.py: EngineOptions) would show up there first, as a crashed benchmark. A scope-aware static check: every name a function loads is bound in
+    that function, at module level, or a builtin."""
+    import ast
+    import builtins
+    for fn_ in ("bench.py", "run.py", "__graft_entry__.py"):
+        tree = ast.parse(open(os.path.join(ROOT, fn_)).read())
+        mod = set(dir(builtins)) | {"__file__", "__name__"}
+        for n in tree.body:
+            if isinstance(n, (ast.Import, ast.ImportFrom)):
+                mod |= {(a.asname or a.name).split(".")[0] for a in n.names}
+            elif isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+                mod.add(n.name)
+            elif isinstance(n, (ast.Assign, ast.AugAssign, ast.AnnAssign, ast.If, ast.Try, ast.With, ast.For)):
+                mod |= {x.id for x in ast.walk(n) if isinstance(x, ast.Name) and isinstance(x.ctx, ast.Store)}
+                mod |= {(a.asname or a.name).split(".")[0] for x in ast.walk(n) if isinstance(x, (ast.Import, ast.ImportFrom)) for a in x.names}
+        for f in (n for n in tree.body if isinstance(n, ast.FunctionDef)):
+            bound = set(mod)
+            for n in ast.walk(f):
+                if isinstance(n, (ast.Import, ast.ImportFrom)):
+                    bound |= {(a.asname or a.name).split(".")[0] for a in n.names}
+                elif isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+                    bound.add(n.name)
+                elif isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+                    bound.add(n.id)
+                elif isinstance(n, ast.arg):
+                    bound.add(n.arg)
+                elif isinstance(n, ast.ExceptHandler) and n.name:
+                    bound.add(n.name)
+            used = {n.id for n in ast.walk(f) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+            assert not (used - bound), (fn_, f.name, sorted(used - bound))
