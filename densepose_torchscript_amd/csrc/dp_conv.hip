@@ -983,88 +983,140 @@ __global__ __launch_bounds__(256, 1) void conv1x1_stream_kernel(const ConvArgs p
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)((long long)p.M * p.osW * 2), 0x00020000);
   const int col_b = (n0 + fq * 8) * 2;   // byte offset of this lane's first run inside a pixel's channel row
 
-  u32x4 a[KP][TP];        // pixel fragments (MFMA B operand): pixel fr of tile j, K chunk fq of plane kp
-  u32x4 r[TP][NB * 2];    // residual: the 8 runs of 8 consecutive couts this lane stores per pixel
+  // Round 6 (profiles/r6_stream_kernel.txt): ONE wave per SIMD has nobody to hide behind. Until round 5 a tile was: per (K plane, cout
+  // block) four weight-fragment reads from LDS, a wait, eight MFMAs - an exposed LDS latency per group, 32 groups per tile, about as long as
+  // the tile's MFMAs - then the epilogue of all 16 runs on its own. Now
+  //   * the loop runs cout block by cout block (K planes inner): block b's accumulators are final after its KP planes, and its epilogue -
+  //     bias, residual, ReLU, pack, four stores - rides in the MFMAs' shadow of block b + 1 (of the next tile's block 0 for the last
+  //     block): two blocks of accumulators alive instead of all of them;
+  //   * the weight fragments of group g + 1 are read while group g multiplies;
+  //   * the pixel fragments of the NEXT tile land in a second register set during the whole current tile (they were refilled plane by plane,
+  //     which only works when the planes are the outer loop).
+  // Every accumulator still sees K planes 0 .. KP - 1 in order: the bits are those of the LDS-ring kernels as before.
+  constexpr int UB = TP * 2;            // epilogue units of a cout block: (pixel half j, run pair h) = 8 couts x 16 pixels x 4 lanes each
+  constexpr int OOBS = 0x7ffffff0;
+  u32x4 aA[KP][TP], aB[KP][TP];         // pixel fragments (MFMA B operand) of the current / the next tile: pixel fr of half j, K chunk fq of plane kp
+  u32x4 r[TP][NB * 2];                  // residual: the runs of 8 consecutive couts this lane stores per pixel
+  auto load_pixels = [&](u32x4 (&dst)[KP][TP], int wtile, auto kpp) __attribute__((always_inline)) {
+    constexpr int kp = decltype(kpp)::value;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) dst[kp][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (wtile * 32 + j * 16 + fr) * in_pitch + fq * 16 + kp * 64, 0, 0);
+  };
+  static_for<0, KP>([&](auto kpp) { load_pixels(aA, wt, kpp); });
 #pragma unroll
   for (int j = 0; j < TP; ++j) {
-    const int m = wt * 32 + j * 16 + fr;
+    const int ro = (has_res ? res_row_off(wt * 32 + j * 16 + fr) : 0) + col_b;
 #pragma unroll
-    for (int kp = 0; kp < KP; ++kp) a[kp][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, m * in_pitch + fq * 16 + kp * 64, 0, 0);
-    if (has_res) {
-      const int ro = res_row_off(m);
-#pragma unroll
-      for (int q = 0; q < NB * 2; ++q) r[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro + col_b + q * 64, 0, 0);
-    }
+    for (int q = 0; q < NB * 2; ++q)       // (the last block's runs are loaded by the first tile itself: see epi_unit's refill)
+      r[j][q] = (has_res && q < (NB - 1) * 2) ? __builtin_amdgcn_raw_buffer_load_b128(rs_res, ro + q * 64, 0, 0) : u32x4{0u, 0u, 0u, 0u};
   }
-
-  for (; wt < n_wt; wt += wt_step) {
-    int m_cur[TP], m_nxt[TP];
+  auto wfrag = [&](auto gg, u32x4 (&wf)[4]) __attribute__((always_inline)) {
+    constexpr int g = decltype(gg)::value;
+    constexpr int b = g / KP, kp = g % KP;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const u32x4*>(rd_w + kp * W_PLANE + (b * 64 + i * 16) * 64);
+  };
+  // epilogue unit (j, h) of cout block b out of `acc`: store at o_off[j] (out of range = nothing stored), then refill the residual registers
+  // it has consumed with the values at r_off[j] - the same run of the tile whose epilogue uses them next
+  auto epi_unit = [&](f32x4 (&acc)[4][TP], const int (&o_off)[TP], const int (&r_off)[TP], auto bb, auto uu) __attribute__((always_inline)) {
+    constexpr int b = decltype(bb)::value, u = decltype(uu)::value;
+    constexpr int j = u >> 1, h = u & 1, q = 2 * b + h;
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + q * 32 + fq * 8);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_s + q * 32 + fq * 8 + 4);
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = acc[2 * h][j][k] + b0[k];
+      v[4 + k] = acc[2 * h + 1][j][k] + b1[k];
+    }
+    if (has_res) {
+      const u32x4 rv = r[j][q];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[2 * k] += Elem<T>::unpack(rv[k] & 0xffffu);
+        v[2 * k + 1] += Elem<T>::unpack(rv[k] >> 16);
+      }
+      r[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, r_off[j] + q * 64, 0, 0);
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    u32x4 pk;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pk[k] = Elem<T>::pack2(v[2 * k], v[2 * k + 1]);
+    __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, o_off[j] + q * 64, 0, 0);
+  };
+  f32x4 accP[2][4][TP];                 // the block being accumulated and the block whose epilogue is pending
+  int o_prev[TP];
+#pragma unroll
+  for (int j = 0; j < TP; ++j) o_prev[j] = OOBS;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j) accP[0][i][j] = accP[1][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // one tile; PAR = its parity: which pixel set is current, and (for an odd block count) which accumulator set block 0 takes
+  auto tile = [&](auto par_) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_)::value;
+    u32x4 (&acur)[KP][TP] = PAR ? aB : aA;
+    u32x4 (&anxt)[KP][TP] = PAR ? aA : aB;
+    int o_cur[TP], r_cur[TP], r_nxt[TP];
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
-      m_cur[j] = wt * 32 + j * 16 + fr;
-      m_nxt[j] = m_cur[j] + wt_step * 32;    // next tile of this wave (past the end: out of range, see above)
+      const int m_cur = wt * 32 + j * 16 + fr, m_nxt = m_cur + wt_step * 32;      // (past the end: out of range, see above)
+      o_cur[j] = m_cur < p.M ? m_cur * out_pitch + col_b : OOBS;
+      r_cur[j] = (has_res ? res_row_off(m_cur) : 0) + col_b;
+      r_nxt[j] = (has_res ? res_row_off(m_nxt) : 0) + col_b;
     }
-    f32x4 acc[NB][4][TP];
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < TP; ++j) acc[b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kp = 0; kp < KP; ++kp) {
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        u32x4 wf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const u32x4*>(rd_w + kp * W_PLANE + (b * 64 + i * 16) * 64);
+    u32x4 wf[2][4];
+    wfrag(std::integral_constant<int, 0>{}, wf[0]);
+    static_for<0, NB * KP>([&](auto gg) {
+      constexpr int g = decltype(gg)::value;
+      constexpr int b = g / KP, kp = g % KP;
+      constexpr int S = (b + PAR * (NB & 1)) & 1;          // accumulator set of this block; the pending block's is 1 - S
+      if constexpr (g + 1 < NB * KP) wfrag(std::integral_constant<int, (g + 1 < NB * KP ? g + 1 : 0)>{}, wf[(g + 1) & 1]);
+      if constexpr (b == 0) load_pixels(anxt, wt + wt_step, std::integral_constant<int, kp>{});      // the next tile's pixels, a plane per group
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kp == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < TP; ++j) Mma<T>::run(wf[i], a[kp][j], acc[b][i][j]);
-        __builtin_amdgcn_sched_barrier(0);   // keep the weight fragments of one cout block live at a time
+          for (int j = 0; j < TP; ++j) accP[S][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      // plane kp of the current tile is consumed: refill its registers with the next tile
 #pragma unroll
-      for (int j = 0; j < TP; ++j) a[kp][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, m_nxt[j] * in_pitch + fq * 16 + kp * 64, 0, 0);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) Mma<T>::run(wf[g & 1][i], acur[kp][j], accP[S][i][j]);
       __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- epilogue: lane = pixel fr of tile j, runs of 8 consecutive couts (store_tile's layout, 4 cout blocks)
+      // the pending block's epilogue units of this group: block b - 1 of this tile, or the last block of the previous tile
+      static_for<(kp * UB) / KP, ((kp + 1) * UB) / KP>([&](auto uu) {
+        if constexpr (b == 0) epi_unit(accP[1 - S], o_prev, r_cur, std::integral_constant<int, NB - 1>{}, uu);
+        else epi_unit(accP[1 - S], o_cur, r_nxt, std::integral_constant<int, (b > 0 ? b - 1 : 0)>{}, uu);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
 #pragma unroll
-    for (int j = 0; j < TP; ++j) {
-      const int o_off = m_cur[j] * out_pitch + col_b;
-      const int r_off = (has_res ? res_row_off(m_nxt[j]) : 0) + col_b;
+    for (int j = 0; j < TP; ++j) o_prev[j] = o_cur[j];
+  };
+  bool odd = false;        // parity of the last tile run
+  for (;;) {
+    tile(std::integral_constant<int, 0>{});
+    wt += wt_step;
+    odd = false;
+    if (wt >= n_wt) break;
+    tile(std::integral_constant<int, 1>{});
+    wt += wt_step;
+    odd = true;
+    if (wt >= n_wt) break;
+  }
+  // drain: the last tile's last block (nothing left to refill)
+  {
+    int r_none[TP];
 #pragma unroll
-      for (int q = 0; q < NB * 2; ++q) {
-        const int b = q >> 1, h = q & 1;
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + q * 32 + fq * 8);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_s + q * 32 + fq * 8 + 4);
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          v[k] = acc[b][2 * h][j][k] + b0[k];
-          v[4 + k] = acc[b][2 * h + 1][j][k] + b1[k];
-        }
-        if (has_res) {
-          const u32x4 rv = r[j][q];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v[2 * k] += Elem<T>::unpack(rv[k] & 0xffffu);
-            v[2 * k + 1] += Elem<T>::unpack(rv[k] >> 16);
-          }
-          r[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, r_off + q * 64, 0, 0);  // the next tile's run
-        }
-        if (p.relu) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-        }
-        u32x4 pk;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pk[k] = Elem<T>::pack2(v[2 * k], v[2 * k + 1]);
-        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, o_off + q * 64, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
+    for (int j = 0; j < TP; ++j) r_none[j] = OOBS;
+    constexpr int SL0 = (NB - 1) & 1, SL1 = (NB - 1 + (NB & 1)) & 1;
+    if (!odd) static_for<0, UB>([&](auto uu) { epi_unit(accP[SL0], o_prev, r_none, std::integral_constant<int, NB - 1>{}, uu); });
+    else static_for<0, UB>([&](auto uu) { epi_unit(accP[SL1], o_prev, r_none, std::integral_constant<int, NB - 1>{}, uu); });
   }
 }
 
