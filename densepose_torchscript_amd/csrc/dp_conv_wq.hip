@@ -506,31 +506,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws1_kernel(const WsqArgs p) {
   if (nst <= 0) return;
 
   const int cgrp = slice * 64 + g * 32;
-  u32x4 wq[72];       // [cout half c'][plane s = channel block x tap]
-  {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int L = cgrp + 16 * (c ^ h) + fr, l64 = L & 63;
-      const int rem = l64 & 31;
-      const int phys = (L & ~63) + (((l64 >> 5) * 2 + ((rem >> 2) & 1)) * 16) + (rem >> 3) * 4 + (rem & 3);   // pack.py's row permutation
-      const unsigned char* __restrict__ w = reinterpret_cast<const unsigned char*>(p.w) + dp_wtile_off(phys, h * 36, fq, 72);
-#pragma unroll
-      for (int s = 0; s < 36; ++s) wq[c * 36 + s] = *reinterpret_cast<const u32x4*>(w + s * 1024);
-    }
-#pragma unroll
-    for (int s = 0; s < 72; ++s) {      // register classes pinned once (see conv3x3_wsq_kernel)
-      if (s < kWqAgprFrags) asm volatile("" : "+a"(wq[s]));
-      else asm volatile("" : "+v"(wq[s]));
-    }
-  }
-  // initial accumulator values: the bias in the h = 0 wave (half c', register e = cout 16 c' + 4 fq + e of the group), zero in the other
-  f32x4 binit[2];
-  {
-    const float m = h == 0 ? 1.f : 0.f;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) binit[c] = *reinterpret_cast<const f32x4*>(p.bias + cgrp + 16 * c + 4 * fq) * m;
-  }
-
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_post = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(POST ? p.post : p.in), 0, POST ? p.post_bytes : 0u, 0x00020000);
@@ -595,6 +570,32 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws1_kernel(const WsqArgs p) {
     const unsigned rb = row_base(st_c, 2 + wave, true);
     static_for<0, PPR>([&](auto prr) { fetch_piece(sb, rb, prr); });
   }
+  // ---- the weights AFTER the first step's row fetches are in flight (both come out of L2; the rows land while the 72 fragment loads run)
+  u32x4 wq[72];       // [cout half c'][plane s = channel block x tap]
+  {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int L = cgrp + 16 * (c ^ h) + fr, l64 = L & 63;
+      const int rem = l64 & 31;
+      const int phys = (L & ~63) + (((l64 >> 5) * 2 + ((rem >> 2) & 1)) * 16) + (rem >> 3) * 4 + (rem & 3);   // pack.py's row permutation
+      const unsigned char* __restrict__ w = reinterpret_cast<const unsigned char*>(p.w) + dp_wtile_off(phys, h * 36, fq, 72);
+#pragma unroll
+      for (int s = 0; s < 36; ++s) wq[c * 36 + s] = *reinterpret_cast<const u32x4*>(w + s * 1024);
+    }
+#pragma unroll
+    for (int s = 0; s < 72; ++s) {      // register classes pinned once (see conv3x3_wsq_kernel)
+      if (s < kWqAgprFrags) asm volatile("" : "+a"(wq[s]));
+      else asm volatile("" : "+v"(wq[s]));
+    }
+  }
+  // initial accumulator values: the bias in the h = 0 wave (half c', register e = cout 16 c' + 4 fq + e of the group), zero in the other
+  f32x4 binit[2];
+  {
+    const float m = h == 0 ? 1.f : 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) binit[c] = *reinterpret_cast<const f32x4*>(p.bias + cgrp + 16 * c + 4 * fq) * m;
+  }
+
   st_n = st_c;
   advance(st_n);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
