@@ -41,6 +41,12 @@
 #ifndef DP_TAIL_TP
 #define DP_TAIL_TP 1   // 16-pixel MFMA tiles per wave tile
 #endif
+#ifndef DP_STRIP_DRAIN
+#define DP_STRIP_DRAIN 0   // strip walker, experiment: drain the job's first loads before the row loop (see there; measured: no change)
+#endif
+#ifndef DP_STRIP_AHEAD
+#define DP_STRIP_AHEAD 2   // strip walker: K steps the weight-fragment reads run ahead of the MFMAs (register sets = this + 1)
+#endif
 
 namespace {
 
@@ -357,6 +363,11 @@ struct StripArgs {
   int n_strips, n_seg, seg_rows, n_jobs;
 };
 
+#if DP_EXP & 64   // ablation (timing only): no MFMAs, one VALU op keeps the operands alive
+#define STRIP_MMA(a, b, c) ((c)[0] += __builtin_bit_cast(float, (a)[0] ^ (b)[0]))
+#else
+#define STRIP_MMA(a, b, c) Mma<T>::run(a, b, c)
+#endif
 template <typename T, bool HAS_NEXT, bool HAS_SC>
 __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripArgs sa) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
@@ -474,21 +485,31 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
     for (int b = 0; b < RB; ++b)
 #pragma unroll
       for (int k = 0; k < 2; ++k) rres[b][k] = res_load(r0, b, k);
+#if DP_STRIP_DRAIN
+    // The compiler's s_waitcnt at the row loop's header is the minimum over BOTH ways into it: behind the job's first loads above, the
+    // residual lines are the youngest operations in flight (0 .. 7 behind them), so every ITERATION waited with vmcnt(2) / vmcnt(3) - for all
+    // but the last two stores of the previous row - where the loop's own order leaves 10 - 18 operations behind those loads. With nothing
+    // in flight at the loop's entry the header's count is the loop's own. (One full drain per job of seg_rows rows.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+#endif
 
     for (int r = r0; r < r1; ++r) {
       if (!(DP_EXP & 1)) load_row(r + 2, row[3]);
       const int orow = (img + r) * p.W;      // first pixel of this output row
 
-      u32x4 wfr[3][4];      // weight fragments: three register sets, the reads run two K steps ahead of the MFMAs
+      constexpr int AH = DP_STRIP_AHEAD;
+      u32x4 wfr[AH + 1][4]; // weight fragments: AH + 1 register sets, the reads run AH K steps ahead of the MFMAs
       u32x4 bfr[3][2];      // B fragments of the kernel row being multiplied: [dx][channel block]
       u32x4 tf[2];          // t2 (conv3's B fragments)
       u32x4 xf[8];          // block output (conv1''s B fragments)
       u32x4 rfr[RB][2];     // residual runs of the four 64-cout blocks (fragment shape); HAS_SC: the block input's two K planes
       f32x4 acc[4];
+      static_for<0, AH>([&](auto ss) {
+        constexpr int S = decltype(ss)::value;
+        const unsigned char* nx = tail_wfrag_addr<S, C3>(w2_s, w3_s, w1_s) + rd;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wfr[0][i] = *reinterpret_cast<const u32x4*>(w2_s + i * 1024 + rd);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wfr[1][i] = *reinterpret_cast<const u32x4*>(w2_s + 4096 + i * 1024 + rd);
+        for (int i = 0; i < 4; ++i) wfr[S][i] = *reinterpret_cast<const u32x4*>(nx + i * 1024);
+      });
 
       // natural-layout t1 row dy -> LDS -> the 6 fragments of kernel row dy
       auto stage_row = [&](const u32x4 (&src)[3]) __attribute__((always_inline)) {
@@ -513,11 +534,13 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
 
       static_for<0, NSTEP>([&](auto kk) {
         constexpr int K = decltype(kk)::value;
-        u32x4 (&wf)[4] = wfr[K % 3];
-        if constexpr (K + 2 < NSTEP) {   // weight fragments of step K + 2 fly while the MFMAs of steps K and K + 1 run
-          const unsigned char* nx = tail_wfrag_addr<K + 2, C3>(w2_s, w3_s, w1_s) + rd;
+        u32x4 (&wf)[4] = wfr[K % (AH + 1)];
+        if constexpr (K + AH < NSTEP) {   // weight fragments of step K + AH fly while the MFMAs of steps K .. K + AH - 1 run
+          const unsigned char* nx = tail_wfrag_addr<K + AH, C3>(w2_s, w3_s, w1_s) + rd;
+          if (!(DP_EXP & 32) || K < 1) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) wfr[(K + 2) % 3][i] = *reinterpret_cast<const u32x4*>(nx + i * 1024);
+            for (int i = 0; i < 4; ++i) wfr[(K + AH) % (AH + 1)][i] = *reinterpret_cast<const u32x4*>(nx + i * 1024);
+          }
         }
         if constexpr (K == 0 || (K >= 18 && K < K3END && (K - 18) % C3 == 0) || K == K3END) {
 #pragma unroll
@@ -527,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
           // ---- conv2, K plane K = (kernel row dy, column tap dx, channel block cb)
           constexpr int dy = K / 6, dx = (K % 6) >> 1, cb = K & 1;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) Mma<T>::run(wf[i], bfr[dx][cb], acc[i]);
+          for (int i = 0; i < 4; ++i) STRIP_MMA(wf[i], bfr[dx][cb], acc[i]);
           if constexpr (K >= 1 && K <= RB) {
             // residual of 64-cout block K - 1 (the buffer is idle between two kernel rows): whole lines -> LDS -> the two
             // runs this lane adds in conv3's epilogue; the line registers are refilled with the next row's residual
@@ -561,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
           // ---- conv3, 64-cout block b, K plane sp (planes 2, 3: the projection shortcut over the block input)
           constexpr int b = (K - 18) / C3, sp = (K - 18) % C3;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) Mma<T>::run(wf[i], sp < 2 ? tf[sp & 1] : rfr[0][sp & 1], acc[i]);
+          for (int i = 0; i < 4; ++i) STRIP_MMA(wf[i], sp < 2 ? tf[sp & 1] : rfr[0][sp & 1], acc[i]);
           if constexpr (sp == 0 && b > 0) flush_out(b - 1);      // the previous block's lines, one step after they were written
           if constexpr (sp == C3 - 1) {
 #pragma unroll
@@ -596,7 +619,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
           // ---- conv1' of the next block: K = the 256 channels just produced (plane q = run q above)
           constexpr int q = K - 26;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) Mma<T>::run(wf[i], xf[q], acc[i]);
+          for (int i = 0; i < 4; ++i) STRIP_MMA(wf[i], xf[q], acc[i]);
           if constexpr (q == 0) flush_out(3);
           if constexpr (q == 7) {
 #pragma unroll
@@ -622,7 +645,7 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
             }
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (!(DP_EXP & 8)) __builtin_amdgcn_sched_barrier(0);
       });
       // the three live rows slide down by one
 #pragma unroll

@@ -86,6 +86,7 @@ class Engine(LayerOps, Stages):
         self.group_deconv = bool(opt.group_deconv)   # A/B knob: 0 = the predictor's four sub-pixel convolutions as four launches
         self.split_k_on = bool(opt.split_k_on)   # A/B knob: layers with PackedConv.split_k run unsplit
         self.decoder_fold = bool(opt.decoder_fold)      # 16-bit modes: the decoder's level sum in the conv epilogues (post_res) instead of a merge pass
+        self.rpn_split_min_hw = int(opt.rpn_split_min_hw)   # RPN levels this large: hidden layer on class 10, heads as a second launch
         self._shared_chip = 0         # dp_conv_params.shared_chip of the launches being issued: 1 beside other large launches, 2 beside the top-k / NMS chain
         self.decoder_after_rpn_heads = bool(opt.decoder_after_rpn_heads)   # where the decoder's side stream forks (see _phase_a)
         self._side_streams = {}
@@ -266,11 +267,10 @@ class Engine(LayerOps, Stages):
             pinned = self._pinned_counts(("eager", slot), n)
             pinned.copy_(st["det_counts"], non_blocking=True)
         else:
-            # everything that changes the captured launch sequence is part of the key
             # every switch that changes the captured launch sequence is part of the key: toggling one on a live engine captures anew
             key = (shape, hwc, slot, self.overlap_decoder, self.decoder_after_rpn_heads, self.fuse_bottleneck, self.fuse_rpn_head,
                    self.fuse_stem_pool, self.fork_levels, self.nms_reference, self.decoder_fold, self.fuse_shortcut, self.fuse_sc_tail,
-                   self.fuse_pair, self.group_deconv, self.split_k_on)
+                   self.fuse_pair, self.group_deconv, self.split_k_on, self.rpn_split_min_hw)
             entry = self._graphs.pop(key, None)
             if entry is None:
                 # every (stream slot / pipeline lane) of one geometry needs a graph of its own: never cap below the slots in use,

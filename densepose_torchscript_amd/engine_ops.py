@@ -196,6 +196,19 @@ class LayerOps:
         self.flops_last += flops
         return Act(out, x.N, Ho, Wo, layer.cout)
 
+    def kernel_class(self, layer, x, relu=True):
+        """the kernel class (include/densepose_hip.h) a plain stride-1 launch of `layer` on x lands on"""
+        if layer.stride != 1:
+            return -1
+        p = L.ConvParams()
+        p.N, p.H, p.W, p.Cin, p.Ho, p.Wo, p.Cout = x.N, x.H, x.W, x.C, x.H, x.W, layer.cout
+        p.Cout_w, p.Kpad, p.stride, p.ntaps, p.dtype, p.relu = layer.cout_w, layer.kpad, 1, layer.ntaps, self.dt, 1 if relu else 0
+        p.hi_off, p.wi_off = layer.hi_off, layer.wi_off
+        p.osN, p.osH, p.osW = x.H * x.W * layer.cout, x.W * layer.cout, layer.cout
+        p.out = 4096                      # placeholder: only NULL / non-NULL matters to the class query
+        p.shared_chip = int(self._shared_chip)
+        return self.lib.dp_conv2d_kernel_class(C.byref(p))
+
     def head_fusable(self, layer, x):
         """True when dp_conv2d_nhwc can apply a fused 1x1 head in this layer's epilogue for input x: the launch lands on the
         256-cout LDS-ring kernel (all 256 channels of a pixel in one workgroup), 16-bit storage."""

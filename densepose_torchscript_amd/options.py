@@ -21,12 +21,16 @@ class EngineOptions:
     decoder_after_rpn_heads: bool = True    # where the decoder's side stream forks (engine._phase_a)
     fuse_resize: bool = True                # device resize at scale != 1 fused with the preprocess
     identity_resize: bool = True            # frames that already have the test size skip the two resize passes
+    # RPN levels with at least this many pixels per image run the hidden 3x3 layer on the one-wave-per-SIMD kernel (class 10) and the two
+    # 1x1 heads as a second launch, instead of the LDS-ring kernel with the heads in its epilogue; 0 = never (engine_stages.rpn)
+    rpn_split_min_hw: int = 0
 
     # field -> environment variable of the command-line tools (historical names)
     ENV: typing.ClassVar[dict] = {
         "fork_levels": "DP_FORK", "frames_direct": "DP_FRAMES_DIRECT", "fuse_shortcut": "DP_FUSE_SHORTCUT", "fuse_sc_tail": "DP_FUSE_SC_TAIL",
         "fuse_pair": "DP_FUSE_PAIR", "group_deconv": "DP_GROUP_DECONV", "split_k_on": "DP_SPLIT_K", "decoder_fold": "DP_DECODER_FOLD",
-        "decoder_after_rpn_heads": "DP_DEC_LATE", "fuse_resize": "DP_FUSE_RESIZE", "identity_resize": "DP_IDENTITY_RESIZE"}
+        "decoder_after_rpn_heads": "DP_DEC_LATE", "fuse_resize": "DP_FUSE_RESIZE", "identity_resize": "DP_IDENTITY_RESIZE",
+        "rpn_split_min_hw": "DP_RPN_SPLIT"}
 
     @classmethod
     def from_env(cls, env=None):
