@@ -576,17 +576,21 @@ __global__ __launch_bounds__(kScanThreads) void nms_scan_kernel(const float* __r
       const unsigned long long cur_v = remv[c];
       unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur_v >> 32)) << 32) |
                                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur_v & 0xffffffffull));
-      unsigned long long km = 0ull;
       const int rows_here = min(64, nvalid - c * 64);
       const int d_lo = (int)(unsigned)(D & 0xffffffffull), d_hi = (int)(unsigned)(D >> 32);
       unsigned long long alive = ~cur & (rows_here >= 64 ? ~0ull : ((1ull << rows_here) - 1ull));
-      while (alive) {
-        const int j = __ffsll((long long)alive) - 1;
+      // A row's word D holds columns ABOVE the row only (nms_mask_kernel: j > i), so a visit never clears the visiting row nor one below it:
+      // a row is kept iff it is alive when its turn comes, and rows whose word is empty suppress nobody - only the others need a turn. With
+      // boxes that barely overlap (64 kept rows per chunk) that is a handful of turns instead of 64.
+      unsigned long long pending = alive & __ballot(D != 0ull);
+      while (pending) {
+        const int j = __ffsll((long long)pending) - 1;
         const unsigned long long dj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(d_hi, j) << 32) |
                                       (unsigned long long)(unsigned)__builtin_amdgcn_readlane(d_lo, j);
-        km |= (1ull << j);
-        alive &= ~(dj | (1ull << j));     // rows below j are already clear, rows above j that j suppresses die
+        alive &= ~dj;                              // rows above j that j suppresses die
+        pending &= alive & ~((2ull << j) - 1ull);  // ... and lose their turn; rows up to j have had theirs
       }
+      const unsigned long long km = alive;
       // the kept rows are written out AFTER the chain (their two dependent loads - sort slot, then box - would sit in it)
       if (lane == 0) { kmask[c] = km; kbase[c] = kept; sh_km = km; }
     }
