@@ -313,7 +313,8 @@ def main():
         for k in state:
             if k.endswith("running_var"):
                 state[k] += 1.0
-    pred = DensePosePredictor(cfg, state, dtype=args.dtype, device=device, resize="device", num_streams=args.streams, use_graphs=not args.no_graphs, options=EngineOptions.from_env())
+    pred = DensePosePredictor(cfg, state, dtype=args.dtype, device=device, resize="device", num_streams=args.streams,
+                              use_graphs=not args.no_graphs, options=EngineOptions.from_env())
     bcast_s, bcast_bytes = 0.0, 0
     if world > 1:
         tensors = pred.engine.model.parameter_tensors()
@@ -383,7 +384,8 @@ def main():
         barrier()
         rate, n = timed_loop(host_frames, 2.0)
         host_rate = {"images_per_s": round(rate, 1), "steps": n,
-                     "note": "frames start in pageable host memory each step (3.2 MB each): gathered into a pinned ring slot, one H2D per batch on a copy stream"}
+                     "note": "frames start in pageable host memory each step (3.2 MB each): gathered into a pinned ring slot, "
+                             "one H2D per batch on a copy stream"}
     multi = None
     if world > 1:
         multi = multi_gpu_record({"sustained_images_per_s": sustained["images_per_s"] if sustained else 0.0,
@@ -466,7 +468,8 @@ def main():
     dflops, dsec, dcalls = agg[dom][:3]
     peak = PEAK_F32_MATRIX if args.dtype == "fp32" else PEAK_BF16_DENSE  # fp16 and bf16 MFMA share the dense peak
     traffic = None
-    for tname in sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json"))), reverse=True):   # newest committed PMC summary that has this kernel
+    # newest committed PMC summary that has this kernel
+    for tname in sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json"))), reverse=True):
         tpath = os.path.join(ROOT, "profiles", tname)
         if traffic is None and os.path.exists(tpath) and args.dtype == "bf16" and args.config == "densepose_rcnn_R_50_FPN_s1x" and args.batch == 8:
             ks = json.load(open(tpath))["kernels"]
@@ -525,9 +528,11 @@ def main():
     # which part is far from either roof
     hbm = {}
     for c, v in agg.items():
-        if c.startswith(("conv1x1_stream_kernel", "bottleneck_tail64_kernel", "bottleneck_pair128_kernel", "stem_pool_kernel", "conv1x1_pws_kernel", "conv1x1_pwq_kernel")) and v[1] > 0:
+        if v[1] > 0 and c.startswith(("conv1x1_stream_kernel", "bottleneck_tail64_kernel", "bottleneck_pair128_kernel", "stem_pool_kernel",
+                                      "conv1x1_pws_kernel", "conv1x1_pwq_kernel")):
             hbm[c] = {"bound": "hbm", "achieved": round(v[3] / v[1] / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": round(v[3] / v[1] / PEAK_HBM, 4),
-                      "alg_mb_per_step": round(v[3] / args.steps / 1e6, 1), "ms_per_step": round(1e3 * v[1] / args.steps, 3), "calls_per_step": v[2] // args.steps,
+                      "alg_mb_per_step": round(v[3] / args.steps / 1e6, 1), "ms_per_step": round(1e3 * v[1] / args.steps, 3),
+                      "calls_per_step": v[2] // args.steps,
                       "tflops": round(v[0] / v[1] / 1e12, 1)}
     roofline["hbm_bound_classes"] = hbm
     # Flat copies of the nested figures a reader of the first level needs (a consumer that keeps only scalars of `roofline` / `config` still sees
@@ -539,7 +544,8 @@ def main():
         roofline["backbone_frac"] = roofline["backbone"]["frac"]
         roofline["backbone_ms_per_step"] = roofline["backbone"]["ms_per_step"]
         roofline["backbone_frac_with_per_launch_events"] = roofline["backbone"]["with_per_launch_events"]["frac"]
-        roofline["backbone_method"] = "HIP events around the stem / res2..res5 / FPN stages in a serialized pass WITHOUT per-launch events (rounds 1 - 4 took them from the pass that brackets every launch: backbone_frac_with_per_launch_events)"
+        roofline["backbone_method"] = ("HIP events around the stem / res2..res5 / FPN stages in a serialized pass WITHOUT per-launch events "
+                                       "(rounds 1 - 4 took them from the pass that brackets every launch: backbone_frac_with_per_launch_events)")
         roofline["trunk_frac"] = roofline["trunk"]["frac"]
     for fam_key in ("ring256_family", "wsr_family"):
         if fam_key in roofline:
@@ -553,7 +559,8 @@ def main():
         roofline["event_vs_rocprof"] = round(dev, 4)
         if abs(dev) > 0.05:
             roofline["warning"] = ("the event-timed average launch of %s (%.1f us) differs by %+.1f %% from the committed rocprofv3 average (%.1f us, %s): "
-                                   "another box / clock than the profile's, or the profile is stale" % (dom, roofline["avg_launch_us"], 100 * dev, rp[0], rp[1]))
+                                   "another box / clock than the profile's, or the profile is stale" % (
+                                       dom, roofline["avg_launch_us"], 100 * dev, rp[0], rp[1]))
 
     result = None
     if rank == 0:
@@ -567,7 +574,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.dtype], "data": "synthetic",
             "p50_ms_per_img": round(1e3 * float(np.median(step_times)) / args.batch, 3),
-            "p50_note": "p50 of synchronised batch-%d steps divided by %d (throughput-style); p50_single_frame_ms is the batch-1 call latency" % (args.batch, args.batch),
+            "p50_note": "p50 of synchronised batch-%d steps divided by %d (throughput-style); p50_single_frame_ms is the batch-1 call latency" % (
+                args.batch, args.batch),
             "p50_single_frame_ms": round(1e3 * float(np.median(single_times)), 3) if single_times else None,
             "sustained": sustained, "host_frames": host_rate,
             "config": {"workload": "%s batch=%d/GPU %dx%d uint8 frames resident in HBM, R=%d detections/img (measured %s), synthetic seeded weights"
