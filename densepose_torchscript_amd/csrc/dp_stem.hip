@@ -10,7 +10,7 @@
 //     lines, one step ahead. The B fragment of (conv column tile, kernel row) is one ds_read_b128 at cell (column + lane >> 4).
 //   * the 64 x 224 weight matrix stays in REGISTERS for the whole launch (7 K steps x 4 cout tiles = 112 VGPRs per lane).
 //   * the two new conv rows of a step (2i, 2i + 1; row 2i - 1 is left over from the previous step) are written, bias + ReLU
-//     applied and rounded to the storage type exactly like the separate conv launch, into a 3-slot LDS ring of conv rows
+//     applied and rounded to the storage type exactly like the separate conv launch, into a 5-slot LDS ring of conv rows
 //     (128 columns x 64 channels); the pool then takes the 3 x 3 maximum from LDS and stores whole 128-byte lines.
 //     Positions outside the conv map hold -inf, so the maximum runs over the same elements as F.max_pool2d's padding rule.
 // Same K order and rounding as conv + pool run separately: bit-identical results (tests/test_gpu_kernels.py).
@@ -25,7 +25,8 @@ constexpr int kCells = 132;                 // input cells staged per row: 128 +
 constexpr int kInRow = kCells * 16;         // bytes
 constexpr int kInSlots = 16;
 constexpr int kConvRow = kConvCols * 128;   // bytes: 64 channels x 2 B per column
-constexpr int kStemLds = 3 * kConvRow + kInSlots * kInRow;   // 82,944 B
+constexpr int kConvSlots = 5;               // conv rows 2 i - 3 .. 2 i + 1 are alive while step i is computed and step i - 1 is pooled
+constexpr int kStemLds = kConvSlots * kConvRow + kInSlots * kInRow;   // 115,712 B
 
 struct StemArgs {
   const void* in;
@@ -49,8 +50,8 @@ template <typename T>
 __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemArgs p) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const conv_s = smem;                      // [3][128 columns][128 B]
-  unsigned char* const in_s = smem + 3 * kConvRow;         // [16][132 cells][16 B]
+  unsigned char* const conv_s = smem;                      // [5][128 columns][128 B]
+  unsigned char* const in_s = smem + kConvSlots * kConvRow;   // [16][132 cells][16 B]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemArgs p) {
       }
       const int col = 16 * t + fr;
       const bool col_ok = (unsigned)(cb + col) < (unsigned)p.Wc;
-      unsigned char* const dst = conv_s + ((y + 3) % 3) * kConvRow;
+      unsigned char* const dst = conv_s + ((y + kConvSlots) % kConvSlots) * kConvRow;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float v[8];
@@ -139,31 +140,17 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemArgs p) {
       conv_tile(2 * i0 - 1, wave);
     } else {
       const u32x4 ninf = {NEG_INF2, NEG_INF2, NEG_INF2, NEG_INF2};
-      for (int idx = tid; idx < kConvRow / 16; idx += 512) *reinterpret_cast<u32x4*>(conv_s + 2 * kConvRow + idx * 16) = ninf;   // slot (-1 + 3) % 3
+      for (int idx = tid; idx < kConvRow / 16; idx += 512) *reinterpret_cast<u32x4*>(conv_s + (kConvSlots - 1) * kConvRow + idx * 16) = ninf;   // row -1
     }
 
-    for (int i = i0; i < i1; ++i) {
-      // the 4 input rows the NEXT step adds (4 i + 6 .. 4 i + 9), fetched now, written to the ring after this step's MFMAs
-      u32x4 pre[2];
-      int pre_dst[2];
-      const bool more = i + 1 < i1;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int idx = tid + q * 512;
-        const int r = idx / kCells, k = idx - r * kCells;
-        const int row = 4 * i + 6 + r;
-        const bool use = more && idx < 4 * kCells;
-        pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, use ? in_off(row, k) : OOB, 0, 0);
-        pre_dst[q] = use ? in_slot(row) + k * 16 : -1;
-      }
-      // conv rows 2 i (waves 0-3) and 2 i + 1 (waves 4-7), two column tiles per wave
-      {
-        const int y = 2 * i + (wave >> 2);
-        conv_tile(y, (wave & 3) * 2);
-        conv_tile(y, (wave & 3) * 2 + 1);
-      }
-      __syncthreads();
-      // 3 x 3 max over conv rows 2 i - 1 .. 2 i + 1, columns 2 j - 1 .. 2 j + 1 (buffer columns 2 jl .. 2 jl + 2); one thread per
+    // Steps, software-pipelined over the two phases (round 6): iteration i computes the conv rows of step i AND pools step i - 1, with ONE
+    // barrier per step. The two waves of a SIMD (w and w + 4) take the phases in opposite order - while one runs its 56 MFMAs the other does
+    // the pool's LDS reads and VALU - where every wave used to wait at a barrier between "all convolve" and "all pool" (two per step, the
+    // matrix pipe idle through the pool). Five conv-row slots: step i writes rows 2 i, 2 i + 1 while the pool still reads 2 i - 3 .. 2 i - 1;
+    // the slots of rows 2 i + 2, 2 i + 3 are those of 2 i - 3, 2 i - 2, free after this iteration's barrier. The 16-slot input ring never
+    // needed the second barrier: the rows fetched for step i + 1 replace rows 4 i - 10 .. 4 i - 7, dead since step i - 2.
+    auto pool_step = [&](int ip) __attribute__((always_inline)) {
+      // 3 x 3 max over conv rows 2 ip - 1 .. 2 ip + 1, columns 2 j - 1 .. 2 j + 1 (buffer columns 2 jl .. 2 jl + 2); one thread per
       // (pooled column, 8-channel chunk); rows / columns outside the map hold -inf
       if (tid < kPoolCols * 8) {
         const int jl = tid >> 3, cidx = tid & 7;
@@ -172,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemArgs p) {
         for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-          const unsigned char* src = conv_s + ((2 * i - 1 + dy + 3) % 3) * kConvRow;
+          const unsigned char* src = conv_s + ((2 * ip - 1 + dy + kConvSlots) % kConvSlots) * kConvRow;
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(src + conv_addr(2 * jl + dx, cidx));
@@ -187,7 +174,35 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemArgs p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) pk[k] = Elem<T>::pack2(m[2 * k], m[2 * k + 1]);
         const int j = j0 + jl;
-        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, j < p.Wo ? ((n * p.Ho + i) * p.Wo + j) * 128 + cidx * 16 : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, j < p.Wo ? ((n * p.Ho + ip) * p.Wo + j) * 128 + cidx * 16 : OOB, 0, 0);
+      }
+    };
+    auto conv_step = [&](int ic) __attribute__((always_inline)) {
+      // conv rows 2 ic (waves 0-3) and 2 ic + 1 (waves 4-7), two column tiles per wave
+      const int y = 2 * ic + (wave >> 2);
+      conv_tile(y, (wave & 3) * 2);
+      conv_tile(y, (wave & 3) * 2 + 1);
+    };
+    for (int i = i0; i <= i1; ++i) {     // (conv row 2 i0 - 1 above is first read by the pool in iteration i0 + 1, behind a barrier)
+      // the 4 input rows the NEXT step adds (4 i + 6 .. 4 i + 9), fetched now, written to the ring behind this iteration's work
+      u32x4 pre[2];
+      int pre_dst[2];
+      const bool more = i + 1 < i1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int idx = tid + q * 512;
+        const int r = idx / kCells, k = idx - r * kCells;
+        const int row = 4 * i + 6 + r;
+        const bool use = more && idx < 4 * kCells;
+        pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, use ? in_off(row, k) : OOB, 0, 0);
+        pre_dst[q] = use ? in_slot(row) + k * 16 : -1;
+      }
+      if (wave < 4) {
+        if (i < i1) conv_step(i);
+        if (i > i0) pool_step(i - 1);
+      } else {
+        if (i > i0) pool_step(i - 1);
+        if (i < i1) conv_step(i);
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q)
