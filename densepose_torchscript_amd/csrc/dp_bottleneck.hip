@@ -41,6 +41,12 @@
 #ifndef DP_TAIL_TP
 #define DP_TAIL_TP 1   // 16-pixel MFMA tiles per wave tile
 #endif
+#ifndef DP_STRIP_NW
+#define DP_STRIP_NW 8      // strip walker: waves per workgroup (experiment builds: 4 = one wave per SIMD)
+#endif
+#ifndef DP_STRIP_ORDER
+#define DP_STRIP_ORDER 0   // strip walker, job order: 0 = segments of a strip first, 1 = strips of a segment first
+#endif
 #ifndef DP_STRIP_DRAIN
 #define DP_STRIP_DRAIN 0   // strip walker, experiment: drain the job's first loads before the row loop (see there; measured: no change)
 #endif
@@ -369,10 +375,10 @@ struct StripArgs {
 #define STRIP_MMA(a, b, c) Mma<T>::run(a, b, c)
 #endif
 template <typename T, bool HAS_NEXT, bool HAS_SC>
-__global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripArgs sa) {
+__global__ __launch_bounds__(DP_STRIP_NW * 64, DP_STRIP_NW / 4) void bottleneck_strip64_kernel(const StripArgs sa) {
   static_assert(sizeof(T) == 2, "16-bit storage only");
   static_assert(!(HAS_NEXT && HAS_SC), "the shortcut's weight planes live where conv1''s would");
-  constexpr int NW = 8;
+  constexpr int NW = DP_STRIP_NW;
   constexpr int C3 = HAS_SC ? 4 : 2;             // K planes behind conv3's accumulators: t2 (2), then the block input (2)
   constexpr int K3END = 18 + 4 * C3;
   constexpr int NSTEP = HAS_NEXT ? 34 : K3END;
@@ -444,10 +450,18 @@ __global__ __launch_bounds__(512, 2) void bottleneck_strip64_kernel(const StripA
   // 16-pixel tensors (residual, output, next t1) use buffer pixels 0..15: fragment shape at dx = 0, line shape i = 0, 1
 
   for (int job = blockIdx.x * NW + wave; job < sa.n_jobs; job += gridDim.x * NW) {
+#if DP_STRIP_ORDER
+    // neighbouring waves walk neighbouring strips of the same rows: a workgroup's eight waves read 8 x 16 pixels of a row side by side
+    const int strip = job % sa.n_strips;
+    const int jt = job / sa.n_strips;
+    const int seg = jt % sa.n_seg;
+    const int n = jt / sa.n_seg;
+#else
     const int seg = job % sa.n_seg;
     const int jt = job / sa.n_seg;
     const int strip = jt % sa.n_strips;
     const int n = jt / sa.n_strips;
+#endif
     const int r0 = seg * sa.seg_rows;
     const int r1 = min(r0 + sa.seg_rows, p.H);
     const int c0 = strip * 16;
@@ -696,7 +710,7 @@ int launch_strip(const TailArgs& a, hipStream_t stream) {
   // rows per job: about two jobs per wave of a full chip (each job re-reads one halo row above and below its rows), at
   // least 4 rows; the split does not touch the arithmetic of a pixel, so results do not depend on it
   const long long cols = (long long)a.N * sa.n_strips;
-  long long want = (2ll * cus * 8 + cols - 1) / cols;
+  long long want = (2ll * cus * DP_STRIP_NW + cols - 1) / cols;
   if (want < 1) want = 1;
   int seg_rows = (int)((a.H + want - 1) / want);
   if (seg_rows < 4) seg_rows = a.H < 4 ? a.H : 4;
@@ -704,9 +718,9 @@ int launch_strip(const TailArgs& a, hipStream_t stream) {
   sa.n_seg = (a.H + seg_rows - 1) / seg_rows;
   const long long jobs = cols * sa.n_seg;
   sa.n_jobs = (int)jobs;
-  int gx = (int)((jobs + 7) / 8);
+  int gx = (int)((jobs + DP_STRIP_NW - 1) / DP_STRIP_NW);
   if (gx > cus) gx = cus;
-  hipLaunchKernelGGL((bottleneck_strip64_kernel<T, HAS_NEXT, HAS_SC>), dim3(gx), dim3(512), kStripLds, stream, sa);
+  hipLaunchKernelGGL((bottleneck_strip64_kernel<T, HAS_NEXT, HAS_SC>), dim3(gx), dim3(DP_STRIP_NW * 64), kStripLds, stream, sa);
   return dp_check_launch("bottleneck_strip64_kernel");
 }
 
