@@ -539,7 +539,9 @@ def main():
     # them), and a cross-check of the event-timed dominant kernel against the newest committed rocprofv3 summary of the same serialized run.
     if traffic:
         roofline["traffic_hbm_bytes_per_launch"] = traffic["hbm_bytes_per_launch"]
-        roofline["traffic_over_algorithmic"] = None
+        # counter traffic over the kernel's algorithmic bytes per launch (input + weights + output, once each): > 1 = re-reads
+        roofline["alg_mb_per_launch"] = round(agg[dom][3] / dcalls / 1e6, 1)
+        roofline["traffic_over_algorithmic"] = round(traffic["hbm_bytes_per_launch"] / max(agg[dom][3] / dcalls, 1.0), 3)
     if "backbone" in roofline:
         roofline["backbone_frac"] = roofline["backbone"]["frac"]
         roofline["backbone_ms_per_step"] = roofline["backbone"]["ms_per_step"]
