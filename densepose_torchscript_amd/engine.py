@@ -336,15 +336,16 @@ class Engine(LayerOps, Stages):
         """DensePose branch (sized by the detection counts R - the one host read-back of the path) + postprocess."""
         n, h, w = st["n"], st["h"], st["w"]
         det_boxes, det_scores, det_counts = st["det_boxes"], st["det_scores"], st["det_counts"]
-        # the returned `scores` are slices of this tensor: with graph replay st[...] lives in the graph's memory pool and is
-        # overwritten by the next replay, so the results get their own copy (n x D floats)
-        det_scores = det_scores.clone()
         if self.keep_intermediates:
-            self.inter["detections"] = (det_boxes, det_scores, det_counts)    # network-input coordinates, before detector_postprocess
+            self.inter["detections"] = (det_boxes, det_scores.clone(), det_counts)    # network-input coordinates, before detector_postprocess
         flops0 = self.flops_last
         slots = self._dp_slots(n, det_boxes.shape[1])
         coarse, fine, u, v = self.densepose_branch(st["feats"], det_boxes, det_counts, st.get("dec"), slots=slots)
         flops_dp = self.flops_last - flops0
+        # the returned `scores` are slices of this tensor: with graph replay st[...] lives in the graph's memory pool and is
+        # overwritten by the next replay, so the results get their own copy (n x D floats). Enqueued BEHIND the DensePose branch: a
+        # device-to-device copy is a blit launch with ~15 us of queue latency, which the branch's first kernel used to wait behind
+        det_scores = det_scores.clone()
         # detector_postprocess (postprocessing.py:43-54); image_size there is [W_pad, H_pad] (Q1) minus the padding
         D = det_boxes.shape[1]
         # per-image scale factors and output sizes: a video / benchmark stream repeats the same geometry batch after batch, so the
