@@ -176,6 +176,44 @@ def test_full_width_batch_equals_single_calls_16bit(dtype, cfgname):
     assert sum(int(w["scores"].shape[0]) for w in want) > 0
 
 
+def test_rpn_split_option_is_batch_invariant_and_close_to_the_default():
+    """EngineOptions.rpn_split_min_hw (an A/B switch, default off: the RPN's large levels on kernel class 10 with the two 1x1 heads as a
+    second launch): chosen by a level's size per image alone, so a frame's result still does not depend on the batch; and against the
+    default path (LDS-ring kernel with the heads in its epilogue - another summation order of the same sums) the proposals move by
+    rounding steps only: same detections within 1.5 px / 0.05."""
+    from densepose_torchscript_amd import get_config, make_synthetic_state
+    from densepose_torchscript_amd.options import EngineOptions
+    from densepose_torchscript_amd.predictor import DensePosePredictor
+    cfg = get_config("densepose_rcnn_R_50_FPN_s1x", ["INPUT.MIN_SIZE_TEST", 256, "INPUT.MAX_SIZE_TEST", 400, "TEST.DETECTIONS_PER_IMAGE", 6])
+    state = make_synthetic_state(cfg, 3)
+    rng = np.random.default_rng(11)
+    imgs = [torch.from_numpy(rng.integers(0, 256, (256, 400, 3), dtype=np.uint8)).cuda() for _ in range(4)]
+    opt = EngineOptions(rpn_split_min_hw=128)
+    single = DensePosePredictor(cfg, state, dtype="bf16", resize="device", options=opt)
+    want = [single(im) for im in imgs]
+    names = set()
+    single.engine.prof = []
+    single(imgs[0])
+    torch.cuda.synchronize()
+    names = {rec[4] for rec in single.engine.prof}
+    single.engine.prof = None
+    assert any(n.startswith("rpn_head ") for n in names), sorted(names)[:8]      # the heads did run as a launch of their own
+    batched = DensePosePredictor(cfg, state, dtype="bf16", resize="device", use_graphs=True, pipeline_depth=2, options=opt)
+    got = batched.predict_batch(imgs)
+    batched.join()
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        for k in g:
+            assert torch.equal(w[k].cpu(), g[k].cpu()), k
+    ref = [DensePosePredictor(cfg, state, dtype="bf16", resize="device")(im) for im in imgs[:2]]
+    for w, r in zip(want, ref):
+        assert abs(int(w["scores"].shape[0]) - int(r["scores"].shape[0])) <= 1
+        n = min(int(w["scores"].shape[0]), int(r["scores"].shape[0]))
+        if n and w["scores"].shape[0] == r["scores"].shape[0]:
+            assert float((w["pred_boxes"] - r["pred_boxes"]).abs().max()) <= 1.5
+            assert float((w["scores"] - r["scores"]).abs().max()) <= 0.05
+
+
 def test_full_width_network_runs_on_the_documented_kernel_classes():
     """DESIGN.md 4.1's table is what the engine really launches: one full-width bf16 frame with the per-launch profile on, and the
     kernel classes of the trunk / FPN / heads are the weight-stationary pointwise kernels (res4 / res5 conv1 + conv3, the laterals, fc2),
