@@ -68,9 +68,10 @@ class Engine(LayerOps, Stages):
         self.use_graphs = False
         self.nms_reference = "cpu"    # "cpu" | "cuda": which torchvision batched_nms strategy switch to reproduce (see above)
         # independent per-level layers on forked streams, bit mask: 1 FPN output convs, 2 RPN levels, 4 decoder scale heads.
-        # Measured (bench.py, 2 runs each, same box): none 889 / 892 img/s, FPN 896 / 897, RPN 915 / 914, FPN + RPN 915 / 903;
-        # the decoder's heads fork from a stream that is itself a fork, which hipGraph capture does not survive (segfault in
-        # capture_end on ROCm 7.2) - so only the RPN levels are forked by default (DP_FORK overrides, for experiments)
+        # Round 3 (bench.py, 2 runs each, same box): none 889 / 892 img/s, FPN 896 / 897, RPN 915 / 914, FPN + RPN 915 / 903 - the RPN
+        # levels were forked from then on. End of round 6 (two pipeline lanes, faster kernels): in line 1178 - 1187 against 1152 - 1165
+        # forked, R_101 958 against 913 - 922 (profiles/r6_ab_fork.txt): the default is 0 again. The decoder's heads fork from a stream
+        # that is itself a fork, which hipGraph capture does not survive (segfault in capture_end on ROCm 7.2): bit 4 only outside capture
         opt = options if options is not None else EngineOptions()     # the A/B switches (options.py); the product path reads no environment
         self.options = opt
         self.fork_levels = int(opt.fork_levels)

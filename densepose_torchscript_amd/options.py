@@ -9,8 +9,10 @@ import typing
 
 @dataclasses.dataclass
 class EngineOptions:
-    # independent per-level layers on forked streams, bit mask: 1 FPN output convs, 2 RPN levels, 4 decoder scale heads (engine.py)
-    fork_levels: int = 2
+    # independent per-level layers on forked streams, bit mask: 1 FPN output convs, 2 RPN levels, 4 decoder scale heads (engine.py).
+    # 0 since the end of round 6: with two pipeline lanes and the decoder's side stream the chip is full, and the RPN levels in line are
+    # 2 % (R_50) to 4.5 % (R_101) faster than forked, equal at batch 1 (profiles/r6_ab_fork.txt); rounds 3 - 5 ran 2 (+ 3 % then)
+    fork_levels: int = 0
     frames_direct: bool = True              # False = stack the frames of a batch first (round 3)
     fuse_shortcut: bool = True              # block-0 projection shortcut as K planes of conv3 (16-bit modes)
     fuse_sc_tail: bool = True               # ... of res2.0 too (stride 1: inside the fused bottleneck tail)

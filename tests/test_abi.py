@@ -186,7 +186,7 @@ def test_product_reads_no_environment_for_its_switches(monkeypatch):
     monkeypatch.setenv("DP_FUSE_PAIR", "0")
     assert EngineOptions().fuse_pair is True                      # the default does not look at the environment ...
     o = EngineOptions.from_env()
-    assert o.fuse_pair is False and o.fork_levels == 2           # ... the tools' constructor does
+    assert o.fuse_pair is False and o.fork_levels == 0           # ... the tools' constructor does
     assert EngineOptions.from_env({"DP_FORK": "3", "DP_DECODER_FOLD": "0"}) == EngineOptions(fork_levels=3, decoder_fold=False)
 
 
