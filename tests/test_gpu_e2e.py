@@ -877,8 +877,10 @@ def test_stream_schedule_does_not_change_the_results(dtype):
     rng = np.random.default_rng(29)
     batches = [[torch.from_numpy(rng.integers(0, 256, (256, 400, 3), dtype=np.uint8)).cuda() for _ in range(3)] for _ in range(3)]
 
-    def run(after_heads, overlap, graphs):
-        pred = DensePosePredictor(cfg, state, dtype=dtype, resize="device", use_graphs=graphs, pipeline_depth=2 if graphs else 1)
+    def run(after_heads, overlap, graphs, fork=0):
+        from densepose_torchscript_amd.options import EngineOptions
+        pred = DensePosePredictor(cfg, state, dtype=dtype, resize="device", use_graphs=graphs, pipeline_depth=2 if graphs else 1,
+                                  options=EngineOptions(fork_levels=fork))
         pred.engine.decoder_after_rpn_heads, pred.engine.overlap_decoder = after_heads, overlap
         outs = [pred.predict_batch(b) for b in batches] + [pred.predict_batch(batches[0])]    # the 4th replays lane 0's graph
         pred.join()
@@ -887,12 +889,13 @@ def test_stream_schedule_does_not_change_the_results(dtype):
 
     want = run(False, False, False)
     assert sum(int(r["scores"].shape[0]) for o in want for r in o) > 0
-    for after_heads, overlap, graphs in ((True, True, True), (False, True, True), (True, True, False)):
-        got = run(after_heads, overlap, graphs)
+    # (fork = EngineOptions.fork_levels: FPN output convolutions / RPN levels on forked streams - the default until round 6 was 2)
+    for after_heads, overlap, graphs, fork in ((True, True, True, 0), (False, True, True, 0), (True, True, False, 0), (True, True, True, 3), (True, True, False, 2)):
+        got = run(after_heads, overlap, graphs, fork)
         for wo, go in zip(want, got):
             for w, g in zip(wo, go):
                 for k in w:
-                    assert torch.equal(w[k], g[k]), (after_heads, overlap, graphs, k)
+                    assert torch.equal(w[k], g[k]), (after_heads, overlap, graphs, fork, k)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
